@@ -1,0 +1,167 @@
+/*
+ * massfuse.h — C ABI of libmassfuse.so: the MI355X (gfx950) implementation of
+ * the MaSS per-frame voxel-map update and inter-map matching hot path.
+ *
+ * The reference (brandontrabucco/mass, /root/reference) is pure Python and has
+ * no FFI of its own; every entry point below replaces a *sequence of torch ops*
+ * inside one reference function, cited as file:line relative to the reference
+ * root.  The host side that keeps the reference's Python call surface lives in
+ * mass_amd/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "device" is a HIP device
+ *     pointer owned by the caller (torch tensors in the Python host); the
+ *     library allocates no persistent device memory.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work
+ *     is enqueued on it and nothing synchronises.  Calls that touch the same
+ *     map / workspace must be stream-ordered by the caller.
+ *   - return value: MF_OK (0) or a negative MF_ERR_* code; the message is
+ *     available from mf_last_error() (thread local).  No C++ exception crosses
+ *     the ABI.
+ *   - axis convention (reference base_projection_layer.py:334-341): world axis
+ *     0 = x <-> bins_x <-> map dim 1 (map_width); world axis 1 = y <-> bins_y
+ *     <-> map dim 0 (map_height, index flipped); world axis 2 = z <-> bins_z
+ *     <-> map dim 2 (map_depth).  The map is fp32 [size0][size1][size2][C],
+ *     C fastest, updated in place.
+ */
+#ifndef MASSFUSE_H
+#define MASSFUSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define MF_API __attribute__((visibility("default")))
+#else
+#define MF_API
+#endif
+
+#define MF_OK             0
+#define MF_ERR_INVALID   -1   /* bad argument (shape, null pointer, unsupported size) */
+#define MF_ERR_WORKSPACE -2   /* workspace too small: see mf_fuse_workspace_bytes     */
+#define MF_ERR_HIP       -3   /* a HIP runtime call or kernel launch failed           */
+
+/* feature kinds (what the per-pixel "features" image holds) */
+#define MF_FEAT_ONES       0  /* features = ones_like(depth), C must be 1 (occupancy_projection_layer.py:159-161) */
+#define MF_FEAT_LABEL_U8   1  /* class id per pixel, uint8;  stands for one_hot(label, C).float()                 */
+#define MF_FEAT_LABEL_I32  2  /* class id per pixel, int32   (semantic_projection_layer.py:203-214)                */
+#define MF_FEAT_LABEL_I64  3  /* class id per pixel, int64                                                         */
+#define MF_FEAT_DENSE_F32  4  /* fp32 [.., C] per pixel      (base_projection_layer.py:320-325)                    */
+
+/* batch semantics */
+#define MF_MODE_SEQUENTIAL 0  /* frame t+1 blends against the result of frame t: n calls of layer.update()         */
+#define MF_MODE_MERGED     1  /* all frames form one point set: the functional API with a leading batch (A.6)      */
+
+/* Voxel map + bin edges.  Replaces the buffers of BaseProjectionLayer
+ * (base_projection_layer.py:153-181). */
+typedef struct mf_grid {
+    int32_t size0, size1, size2;        /* map_height, map_width, map_depth (each <= 1024)            */
+    int32_t channels;                   /* feature_size C                                              */
+    const float *bins_x;                /* device, n_edges_x floats (world axis 0)                     */
+    const float *bins_y;                /* device, n_edges_y floats (world axis 1)                     */
+    const float *bins_z;                /* device, n_edges_z floats (world axis 2)                     */
+    int32_t n_edges_x, n_edges_y, n_edges_z;   /* must be size1+1, size0+1, size2+1                    */
+    float *map;                         /* device fp32 [size0*size1*size2*channels], in place          */
+} mf_grid;
+
+/* A batch of posed RGB-D(+feature) frames.  Replaces the observation dict of
+ * BaseProjectionLayer.update (base_projection_layer.py:309-325). */
+typedef struct mf_frames {
+    int32_t n_frames;
+    int32_t height, width;              /* camera resolution of `depth` and `cam_rays`                 */
+    const float *cam_rays;              /* device [height*width*3]: the layer's `rays` buffer
+                                           (project_camera_rays, projection.py:34-74)                  */
+    const float *poses;                 /* device [n_frames*12]: origin[3] then R[3][3] row-major,
+                                           R = stack([eye x up, up, -eye], -1) (projection.py:104-105),
+                                           computed by the host                                        */
+    const float *depth;                 /* device [n_frames*height*width] metres                       */
+    const void *feat;                   /* device, per feat_kind; NULL for MF_FEAT_ONES                */
+    int32_t feat_kind;
+    int32_t feat_height, feat_width;    /* resolution of `feat`; height%feat_height==0 etc.
+                                           (repeat_interleave upsampling, base_projection_layer.py:322-325) */
+    float min_depth, max_depth;         /* bin_rays min_ray_depth / max_ray_depth (0, 10)              */
+} mf_frames;
+
+MF_API int mf_version(void);
+MF_API const char *mf_last_error(void);
+
+/* ---- parity entry points (one per reference function) --------------------- */
+
+/* transform_rays, projection.py:77-110.  out[f][p][i] = ((r0*R[i][0] + r1*R[i][1]) + r2*R[i][2]).
+ * cam_rays device [n_pixels*3]; poses device [n_frames*12]; out device [n_frames*n_pixels*3]. */
+MF_API int mf_transform_rays(const float *cam_rays, int64_t n_pixels, const float *poses, int32_t n_frames,
+                      float *out, void *stream);
+
+/* bin_rays, projection.py:113-230, per-pixel (uncompacted) form: for every ray
+ * writes the voxel index triple (int64, axis 1 flipped), the three in-voxel
+ * ratios (axis 1 as 1-r) and the validity criterion; invalid pixels get
+ * ratio 0.  origin device [n_frames*3]; rays device [n_frames*n_pixels*3]
+ * (world frame) or, if rays_per_frame == 0, [n_pixels*3] shared by all frames;
+ * depth device [n_frames*n_pixels].  Any output pointer may be NULL. */
+MF_API int mf_bin_rays(const float *bins0, int32_t n0, const float *bins1, int32_t n1,
+                const float *bins2, int32_t n2,
+                const float *origin, const float *rays, int32_t rays_per_frame,
+                const float *depth, int32_t n_frames, int64_t n_pixels,
+                float min_depth, float max_depth,
+                int64_t *ind0, int64_t *ind1, int64_t *ind2,
+                float *ratio0, float *ratio1, float *ratio2, uint8_t *valid, void *stream);
+
+/* Fused a3+a4 exactly as the hot path evaluates them (camera rays + poses ->
+ * indices), same outputs as mf_bin_rays; exists so tests can prove the fused
+ * geometry equals transform_rays followed by bin_rays bit for bit. */
+MF_API int mf_unproject_bin(const mf_grid *grid, const mf_frames *frames,
+                     int64_t *ind_x, int64_t *ind_y, int64_t *ind_z,
+                     float *ratio_x, float *ratio_y, float *ratio_z, uint8_t *valid, void *stream);
+
+/* ---- the hot path ---------------------------------------------------------- */
+
+/* Bytes of device workspace mf_fuse_frames / mf_update_feature_map need for at
+ * most n_points input points (pixels x frames) in n_groups sequential groups
+ * (n_frames for MF_MODE_SEQUENTIAL, 1 for MF_MODE_MERGED).  0 on bad input. */
+MF_API size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int32_t n_groups);
+
+/* BaseProjectionLayer.update for a batch of frames
+ * (base_projection_layer.py:282-343 = transform_rays + bin_rays +
+ * update_feature_map, and the one_hot / ones_like front ends of
+ * semantic_projection_layer.py:203-214 / occupancy_projection_layer.py:159-161).
+ * Updates grid->map in place.  n_frames <= 256 per call.
+ * The workspace needs no initialisation and holds nothing between calls. */
+MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
+                   int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
+
+/* update_feature_map, projection.py:233-351, for already binned points:
+ * ind0/1/2 int64 and ratio0/1/2 fp32 device [n]; feat per feat_kind with one
+ * row per point ([n] labels or [n][C] fp32).  Only grid->size*, channels and
+ * map are read from `grid`. */
+MF_API int mf_update_feature_map(const mf_grid *grid, int64_t n,
+                          const int64_t *ind0, const int64_t *ind1, const int64_t *ind2,
+                          const float *ratio0, const float *ratio1, const float *ratio2,
+                          const void *feat, int32_t feat_kind, float interpolation_weight,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- matching (experimentation.py:261-265, 277-280, 284-287) --------------- */
+
+#define MF_METRIC_L2       0  /* || f0_i - f1_j ||_2, difference form (reference arithmetic)          */
+#define MF_METRIC_L2_GEMM  1  /* sqrt(max(|a|^2 + |b|^2 - 2 a.b, 0)) on fp32 MFMA                      */
+#define MF_METRIC_COSINE   2  /* 1 - a.b / (|a||b|) on fp32 MFMA (not in the reference; config 4 extra) */
+
+/* f0 device [n0][d], f1 device [n1][d], out device [n0][n1], all fp32. */
+MF_API int mf_pairwise_distance(const float *f0, int32_t n0, const float *f1, int32_t n1, int32_t d,
+                         float *out, int32_t metric, void *stream);
+
+/* scipy.optimize.linear_sum_assignment (minimise; rectangular allowed) on a
+ * HOST cost matrix [n0][n1] (float64, row-major).  Writes min(n0,n1) pairs to
+ * row_ind/col_ind (host), rows ascending.  Returns the pair count or <0. */
+MF_API int mf_linear_sum_assignment(const double *cost, int32_t n0, int32_t n1,
+                             int64_t *row_ind, int64_t *col_ind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASSFUSE_H */

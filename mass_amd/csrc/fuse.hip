@@ -1,0 +1,764 @@
+// fuse.hip — the per-frame voxel-map update for gfx950 (MI355X).
+//
+// Replaces, per call, the torch op sequences of the reference's
+//   transform_rays      /root/reference/mass/utils/projection.py:77-110
+//   bin_rays            projection.py:113-230
+//   update_feature_map  projection.py:233-351
+// as driven by BaseProjectionLayer.update (mass/nn/base_projection_layer.py:282-343).
+//
+// Design: the reference's read-modify-write blend
+//     new[v] = sum_k ((1 - iw*w_k)*old[v] + iw*w_k*f_k) * w_k / W[v]
+// is evaluated in its closed form
+//     new[v] = old[v] * (1 - iw*S2/W) + (iw/W) * sum_k w_k^2 f_k ,  W = sum w_k, S2 = sum w_k^2
+// by one workgroup per *map tile* that keeps the tile's voxels in LDS:
+//   1. count   : every pixel is unprojected and binned (bit-exact integer
+//                path), its 2x2x2 footprint is mapped to the <=8 tiles it
+//                overlaps, and (tile, group) bucket sizes are counted with a
+//                per-block LDS hash so one global atomic is issued per
+//                distinct bucket per block;
+//   2. scan    : exclusive prefix sum of the bucket sizes;
+//   3. scatter : the same pass again, now writing a 20-byte point record into
+//                its bucket slot (slot = bucket base + LDS-local rank);
+//   4. fuse    : persistent workgroups pull tiles from a ticket counter, load
+//                the touched voxels of the tile into LDS, and for each group
+//                (= frame, in order) accumulate W and S2 with LDS float
+//                atomics, decay the touched voxels, add the w^2-weighted
+//                features, and finally write the touched voxels back.
+// No global float atomics are used (they run at ~1.3 TB/s and 17x slower when
+// scattered); HBM sees each touched voxel once per call, coalesced along z.
+#include "common.h"
+#include "geometry.h"
+
+namespace mf {
+
+// ----------------------------------------------------------------------------
+// parameters shared by the pipeline kernels (passed by value)
+// ----------------------------------------------------------------------------
+struct FuseParams {
+    // grid
+    int size0, size1, size2, C;
+    Bins bins;                 // b0 = bins_x, b1 = bins_y, b2 = bins_z
+    float *map;
+    // frames (front end 0)
+    int n_frames, H, W;
+    const float *cam, *poses, *depth;
+    const void *feat;
+    int feat_kind, fh, fw, rep_y, rep_x;
+    float min_d, max_d;
+    // binned points (front end 1)
+    const int64_t *i0, *i1, *i2;
+    const float *q0, *q1, *q2;
+    // common
+    long long n_points;
+    int G;                     // sequential groups
+    float iw;
+    // tiling
+    int s0, s1, s2;            // log2 tile extents
+    int nt0, nt1, nt2, n_tiles, n_keys;
+    unsigned magicC;           // ceil(2^32 / C) (0 when C == 1)
+    // workspace
+    int *cursor;               // [n_keys + 1]
+    int *block_sums;
+    int *ticket;
+    uint4 *rec;
+    uint32_t *aux;
+};
+
+struct Point {
+    int k0, k1, k2;            // map dims: 0 = y (flipped), 1 = x, 2 = z
+    float r0, r1, r2;
+    int group;
+};
+
+__device__ __forceinline__ uint32_t read_label(const void *feat, int kind, long long i)
+{
+    if (kind == MF_FEAT_LABEL_U8) return ((const uint8_t *)feat)[i];
+    if (kind == MF_FEAT_LABEL_I32) return (uint32_t)((const int32_t *)feat)[i];
+    const long long v = ((const int64_t *)feat)[i];
+    return (v < 0 || v > 0x7fffffffLL) ? 0xffffffffu : (uint32_t)v;
+}
+
+// Front end 0: pixel of a posed frame -> binned point (a3 + a4).
+// Front end 1: already binned point arrays (functional update_feature_map).
+template <int FRONT>
+__device__ __forceinline__ bool get_point(const FuseParams &P, long long idx, Point &pt, uint32_t &aux)
+{
+    if (FRONT == 0) {
+        const int HW = P.H * P.W;
+        const int f = (int)(idx / HW);
+        const int pix = (int)(idx - (long long)f * HW);
+        const float d = P.depth[idx];
+        const float *pose = P.poses + f * 12;
+        float q0, q1, q2;
+        rotate_ray(pose + 3, P.cam[pix * 3], P.cam[pix * 3 + 1], P.cam[pix * 3 + 2], q0, q1, q2);
+        const float m0 = q0 * d, m1 = q1 * d, m2 = q2 * d;
+        const float p0 = pose[0] + m0, p1 = pose[1] + m1, p2 = pose[2] + m2;
+        int kx, ky, kz; float rx, ry, rz;
+        const bool ok = bin_point(P.bins, p0, p1, p2, d, P.min_d, P.max_d, kx, ky, kz, rx, ry, rz);
+        pt.k0 = ky; pt.k1 = kx; pt.k2 = kz; pt.r0 = ry; pt.r1 = rx; pt.r2 = rz;
+        pt.group = P.G == 1 ? 0 : f;
+        if (ok && P.feat_kind != MF_FEAT_ONES) {
+            const int y = pix / P.W, x = pix - y * P.W;
+            const long long fi = ((long long)f * P.fh + y / P.rep_y) * P.fw + x / P.rep_x;
+            aux = P.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)fi : read_label(P.feat, P.feat_kind, fi);
+        }
+        return ok;
+    } else {
+        const long long a = P.i0[idx], b = P.i1[idx], c = P.i2[idx];
+        const bool ok = a >= 0 && a < P.size0 && b >= 0 && b < P.size1 && c >= 0 && c < P.size2;
+        pt.k0 = (int)a; pt.k1 = (int)b; pt.k2 = (int)c;
+        pt.r0 = P.q0[idx]; pt.r1 = P.q1[idx]; pt.r2 = P.q2[idx];
+        pt.group = 0;
+        if (ok && P.feat_kind != MF_FEAT_ONES)
+            aux = P.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)idx : read_label(P.feat, P.feat_kind, idx);
+        return ok;
+    }
+}
+
+// The <=8 (tile, group) buckets a point's footprint overlaps.
+__device__ __forceinline__ int point_keys(const FuseParams &P, const Point &pt, uint32_t keys[8])
+{
+    const AxisFoot a0 = axis_foot(pt.k0, pt.r0, P.size0);
+    const AxisFoot a1 = axis_foot(pt.k1, pt.r1, P.size1);
+    const AxisFoot a2 = axis_foot(pt.k2, pt.r2, P.size2);
+    const int t0[2] = {a0.lo >> P.s0, a0.hi >> P.s0};
+    const int t1[2] = {a1.lo >> P.s1, a1.hi >> P.s1};
+    const int t2[2] = {a2.lo >> P.s2, a2.hi >> P.s2};
+    const int m0 = t0[0] != t0[1] ? 2 : 1, m1 = t1[0] != t1[1] ? 2 : 1, m2 = t2[0] != t2[1] ? 2 : 1;
+    int n = 0;
+    for (int a = 0; a < m0; ++a)
+        for (int b = 0; b < m1; ++b)
+            for (int c = 0; c < m2; ++c) {
+                const int tile = (t0[a] * P.nt1 + t1[b]) * P.nt2 + t2[c];
+                keys[n++] = (uint32_t)(tile * P.G + pt.group);
+            }
+    return n;
+}
+
+// ----------------------------------------------------------------------------
+// per-block LDS hash: bucket key -> (count, base)
+// ----------------------------------------------------------------------------
+constexpr int BIN_THREADS = 256;
+constexpr int HS_BITS = 11;
+constexpr int HS = 1 << HS_BITS;
+constexpr uint32_t EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ int hash_insert(uint32_t *hkey, int *hcnt, uint32_t key, int &rank)
+{
+    uint32_t h = (key * 2654435761u) >> (32 - HS_BITS);
+    for (int probe = 0; probe < 24; ++probe) {
+        const uint32_t prev = atomicCAS(&hkey[h], EMPTY, key);
+        if (prev == EMPTY || prev == key) { rank = atomicAdd(&hcnt[h], 1); return (int)h; }
+        h = (h + 1) & (HS - 1);
+    }
+    return -1;
+}
+
+template <int FRONT>
+__global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
+{
+    __shared__ uint32_t hkey[HS];
+    __shared__ int hcnt[HS];
+    for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * BIN_THREADS + threadIdx.x;
+    if (idx < P.n_points) {
+        Point pt; uint32_t aux = 0;
+        if (get_point<FRONT>(P, idx, pt, aux)) {
+            uint32_t keys[8];
+            const int n = point_keys(P, pt, keys);
+            for (int i = 0; i < n; ++i) {
+                int rank;
+                if (hash_insert(hkey, hcnt, keys[i], rank) < 0) atomicAdd(&P.cursor[keys[i]], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < HS; s += BIN_THREADS)
+        if (hkey[s] != EMPTY) atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
+}
+
+template <int FRONT>
+__global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
+{
+    __shared__ uint32_t hkey[HS];
+    __shared__ int hcnt[HS];
+    for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * BIN_THREADS + threadIdx.x;
+    Point pt; uint32_t aux = 0;
+    uint32_t keys[8];
+    int slot[8], rank[8];
+    int n = 0;
+    if (idx < P.n_points && get_point<FRONT>(P, idx, pt, aux)) {
+        n = point_keys(P, pt, keys);
+        for (int i = 0; i < n; ++i) slot[i] = hash_insert(hkey, hcnt, keys[i], rank[i]);
+    }
+    __syncthreads();
+    // one returning global atomic per distinct bucket of this block; hcnt becomes the base
+    for (int s = threadIdx.x; s < HS; s += BIN_THREADS)
+        if (hkey[s] != EMPTY) hcnt[s] = atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
+    __syncthreads();
+    if (n > 0) {
+        uint4 r;
+        r.x = (uint32_t)pt.k0 | ((uint32_t)pt.k1 << 10) | ((uint32_t)pt.k2 << 20);
+        r.y = __float_as_uint(pt.r0); r.z = __float_as_uint(pt.r1); r.w = __float_as_uint(pt.r2);
+        for (int i = 0; i < n; ++i) {
+            const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
+            P.rec[pos] = r;
+            if (P.feat_kind != MF_FEAT_ONES) P.aux[pos] = aux;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// exclusive scan of cursor[0 .. n] (n = n_keys + 1 items, last one is 0)
+// ----------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ int block_reduce_sum(int v, int *sh /* [SCAN_THREADS/64] */)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) t += sh[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(const int *__restrict__ data, int n, int *block_sums)
+{
+    __shared__ int sh[SCAN_THREADS / 64];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) s += data[base + i];
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int *data, int n, const int *__restrict__ block_sums)
+{
+    __shared__ int sh[SCAN_THREADS / 64];
+    __shared__ int wsum[SCAN_THREADS / 64];
+    int pre = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_THREADS) pre += block_sums[b];
+    pre = block_reduce_sum(pre, sh);
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? data[base + i] : 0; s += v[i]; }
+    // inclusive scan of the per-thread sums inside the wave, then across waves
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = s;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wsum[w];
+    int run = pre + woff + inc - s;
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) { data[base + i] = run; run += v[i]; }
+}
+
+// ----------------------------------------------------------------------------
+// tile kernel
+// ----------------------------------------------------------------------------
+constexpr int MAX_GROUPS = 256;
+
+__device__ __forceinline__ unsigned div_magic(unsigned n, unsigned magic)   // n / C, magic = ceil(2^32/C), 0 for C == 1
+{
+    return magic ? __umulhi(n, magic) : n;
+}
+
+
+// Visit the corners of point record r that fall inside the tile whose origin
+// is (o0, o1, o2): body(v, w) gets the tile-local voxel id and the corner weight.
+template <class F>
+__device__ __forceinline__ void for_corners(const FuseParams &P, const uint4 &r, int o0, int o1, int o2, F body)
+{
+    const int k0 = r.x & 1023, k1 = (r.x >> 10) & 1023, k2 = (r.x >> 20) & 1023;
+    const AxisFoot a0 = axis_foot(k0, __uint_as_float(r.y), P.size0);
+    const AxisFoot a1 = axis_foot(k1, __uint_as_float(r.z), P.size1);
+    const AxisFoot a2 = axis_foot(k2, __uint_as_float(r.w), P.size2);
+    const int i0[2] = {a0.lo - o0, a0.hi - o0}, i1[2] = {a1.lo - o1, a1.hi - o1}, i2[2] = {a2.lo - o2, a2.hi - o2};
+    const float w0[2] = {a0.wlo, a0.whi}, w1[2] = {a1.wlo, a1.whi}, w2[2] = {a2.wlo, a2.whi};
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+        const int ca = cc >> 2, cb = (cc >> 1) & 1, cd = cc & 1;
+        const unsigned l0 = (unsigned)i0[ca], l1 = (unsigned)i1[cb], l2 = (unsigned)i2[cd];
+        if ((l0 >> P.s0) == 0 && (l1 >> P.s1) == 0 && (l2 >> P.s2) == 0) {
+            const int v = (int)((((l0 << P.s1) | l1) << P.s2) | l2);
+            body(v, corner_weight(w0[ca], w1[cb], w2[cd]));
+        }
+    }
+}
+
+// KIND: 0 = ones (C == 1), 1 = labels, 2 = dense fp32 features
+template <int KIND>
+__global__ __launch_bounds__(1024) void fuse_tiles_kernel(FuseParams P)
+{
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int C = P.C;
+    const int sv = P.s0 + P.s1 + P.s2;
+    const int TV = 1 << sv;
+    float *mapT = smem;                        // [TV][C]
+    float *Wl = mapT + (size_t)TV * C;         // [TV]  W, then iw/W
+    float *Sl = Wl + TV;                       // [TV]  S2, then 1 - iw*S2/W
+    int *offs = (int *)(Sl + TV);              // [MAX_GROUPS + 1]
+    int *misc = offs + MAX_GROUPS + 1;         // [0] ticket, [1] touched count
+    uint32_t *flags = (uint32_t *)(misc + 3);  // [TV]
+    unsigned short *tlist = (unsigned short *)(flags + TV);   // [TV]
+    const int G = P.G;
+    const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
+
+    for (;;) {
+        if (tid == 0) misc[0] = atomicAdd(P.ticket, 1);
+        __syncthreads();
+        const int tile = misc[0];
+        if (tile >= P.n_tiles) break;
+        const int kb = tile * G;
+        for (int g = tid; g <= G; g += NT) offs[g] = (kb + g > 0) ? P.cursor[kb + g - 1] : 0;
+        __syncthreads();
+        const int e0 = offs[0], e1 = offs[G];
+        if (e0 == e1) { __syncthreads(); continue; }
+        const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
+        const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
+
+        // ---- which voxels of the tile does this call touch? -----------------
+        for (int v = tid; v < TV; v += NT) flags[v] = 0;
+        __syncthreads();
+        for (int e = e0 + tid; e < e1; e += NT) {
+            const uint4 r = P.rec[e];
+            for_corners(P, r, o0, o1, o2, [&](int v, float) { flags[v] = 1u; });
+        }
+        __syncthreads();
+
+        // ---- load touched voxels (coalesced along z / channel) ---------------
+        const unsigned n_el = (unsigned)TV * (unsigned)C;
+        for (unsigned i = tid; i < n_el; i += NT) {
+            const unsigned v = div_magic(i, P.magicC);
+            if (flags[v]) {
+                const unsigned c = i - v * C;
+                const int l2 = v & m2, l1 = (v >> P.s2) & m1, l0 = v >> (P.s1 + P.s2);
+                const size_t gv = ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2);
+                mapT[i] = P.map[gv * C + c];
+            }
+        }
+        __syncthreads();
+
+        // ---- groups (frames) in order -----------------------------------------
+        for (int g = 0; g < G; ++g) {
+            const int ga = offs[g], gb = offs[g + 1];
+            if (ga == gb) continue;
+            for (int v = tid; v < TV; v += NT) { Wl[v] = 0.0f; Sl[v] = 0.0f; }
+            if (tid == 0) misc[1] = 0;
+            __syncthreads();
+            for (int e = ga + tid; e < gb; e += NT) {
+                const uint4 r = P.rec[e];
+                for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&Wl[v], w); atomicAdd(&Sl[v], w * w); });
+            }
+            __syncthreads();
+            for (int v = tid; v < TV; v += NT) {
+                const float Wv = Wl[v];
+                if (Wv > 0.0f) {
+                    Sl[v] = 1.0f - P.iw * (Sl[v] / Wv);
+                    Wl[v] = P.iw / Wv;
+                    tlist[atomicAdd(&misc[1], 1)] = (unsigned short)v;
+                }
+            }
+            __syncthreads();
+            const unsigned n_dec = (unsigned)misc[1] * (unsigned)C;
+            for (unsigned i = tid; i < n_dec; i += NT) {
+                const unsigned q = div_magic(i, P.magicC);
+                const unsigned v = tlist[q];
+                const unsigned j = v * C + (i - q * C);
+                mapT[j] *= Sl[v];
+            }
+            __syncthreads();
+            if (KIND == 0) {
+                for (int e = ga + tid; e < gb; e += NT) {
+                    const uint4 r = P.rec[e];
+                    for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&mapT[v], (w * w) * Wl[v]); });
+                }
+            } else if (KIND == 1) {
+                for (int e = ga + tid; e < gb; e += NT) {
+                    const uint4 r = P.rec[e];
+                    const uint32_t label = P.aux[e];
+                    if (label < (uint32_t)C)
+                        for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&mapT[v * C + label], (w * w) * Wl[v]); });
+                }
+            } else {
+                // lanes-per-entry: the smallest power of two >= min(C, 64)
+                int lpe = 1;
+                while (lpe < C && lpe < 64) lpe <<= 1;
+                const int sub = tid & (lpe - 1);
+                const int per = NT / lpe;
+                for (int e = ga + tid / lpe; e < gb; e += per) {
+                    const uint4 r = P.rec[e];
+                    const float *f = (const float *)P.feat + (size_t)P.aux[e] * C;
+                    for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                        const float s = (w * w) * Wl[v];
+                        for (int c = sub; c < C; c += lpe) atomicAdd(&mapT[v * C + c], s * f[c]);
+                    });
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- write back ---------------------------------------------------------
+        for (unsigned i = tid; i < n_el; i += NT) {
+            const unsigned v = div_magic(i, P.magicC);
+            if (flags[v]) {
+                const unsigned c = i - v * C;
+                const int l2 = v & m2, l1 = (v >> P.s2) & m1, l0 = v >> (P.s1 + P.s2);
+                const size_t gv = ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2);
+                P.map[gv * C + c] = mapT[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------
+// parity kernels (a3, a4, fused a3+a4)
+// ----------------------------------------------------------------------------
+__global__ void transform_rays_kernel(const float *__restrict__ cam, long long n_pix,
+                                      const float *__restrict__ poses, int n_frames, float *out)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pix * n_frames) return;
+    const int f = (int)(idx / n_pix);
+    const long long pix = idx - (long long)f * n_pix;
+    float q0, q1, q2;
+    rotate_ray(poses + f * 12 + 3, cam[pix * 3], cam[pix * 3 + 1], cam[pix * 3 + 2], q0, q1, q2);
+    out[idx * 3] = q0; out[idx * 3 + 1] = q1; out[idx * 3 + 2] = q2;
+}
+
+struct BinOut {
+    int64_t *i0, *i1, *i2;
+    float *r0, *r1, *r2;
+    uint8_t *valid;
+};
+
+__device__ __forceinline__ void store_bin(const BinOut &o, long long idx, bool ok, int k0, int k1, int k2,
+                                          float r0, float r1, float r2)
+{
+    if (o.i0) o.i0[idx] = k0;
+    if (o.i1) o.i1[idx] = k1;
+    if (o.i2) o.i2[idx] = k2;
+    if (o.r0) o.r0[idx] = r0;
+    if (o.r1) o.r1[idx] = r1;
+    if (o.r2) o.r2[idx] = r2;
+    if (o.valid) o.valid[idx] = ok ? 1 : 0;
+}
+
+__global__ void bin_rays_kernel(Bins B, const float *__restrict__ origin, const float *__restrict__ rays,
+                                int rays_per_frame, const float *__restrict__ depth, int n_frames,
+                                long long n_pix, float min_d, float max_d, BinOut o)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pix * n_frames) return;
+    const int f = (int)(idx / n_pix);
+    const long long ri = rays_per_frame ? idx : idx - (long long)f * n_pix;
+    const float d = depth[idx];
+    const float m0 = rays[ri * 3] * d, m1 = rays[ri * 3 + 1] * d, m2 = rays[ri * 3 + 2] * d;
+    const float p0 = origin[f * 3] + m0, p1 = origin[f * 3 + 1] + m1, p2 = origin[f * 3 + 2] + m2;
+    int k0, k1, k2; float r0, r1, r2;
+    const bool ok = bin_point(B, p0, p1, p2, d, min_d, max_d, k0, k1, k2, r0, r1, r2);
+    store_bin(o, idx, ok, k0, k1, k2, r0, r1, r2);
+}
+
+__global__ void unproject_bin_kernel(FuseParams P, BinOut o)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P.n_points) return;
+    Point pt; uint32_t aux = 0;
+    const bool ok = get_point<0>(P, idx, pt, aux);
+    // outputs in the reference's (x, y, z) order of bin_rays
+    store_bin(o, idx, ok, pt.k1, pt.k0, pt.k2, pt.r1, pt.r0, pt.r2);
+}
+
+// ----------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------
+static int ilog2_floor(unsigned x) { int l = 0; while ((2u << l) <= x) ++l; return l; }
+
+// Tile extents: the largest power-of-two voxel count whose LDS image
+// (C floats of map + W + S2 + flag + list per voxel) fits ~140 KB, capped at
+// 1024 voxels; z gets up to 8 (16 for >= 1024 voxels) so that HBM runs stay long.
+static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
+{
+    const size_t budget = 140 * 1024 - 4 * (MAX_GROUPS + 8);
+    size_t per_voxel = (size_t)g->channels * 4 + 4 + 4 + 4 + 2;
+    unsigned tv = (unsigned)(budget / per_voxel);
+    if (tv < 1) tv = 1;
+    if (tv > 1024) tv = 1024;
+    int sv = ilog2_floor(tv);
+    s2 = sv >= 10 ? 4 : 3;
+    if (s2 > sv) s2 = sv;
+    const int rem = sv - s2;
+    s1 = (rem + 1) / 2;
+    s0 = rem - s1;
+}
+
+static size_t tile_lds_bytes(int C, int sv)
+{
+    const size_t TV = (size_t)1 << sv;
+    return TV * C * 4 + TV * 4 * 2 + (MAX_GROUPS + 1 + 3) * 4 + TV * 4 + TV * 2 + 16;
+}
+
+struct Layout {
+    size_t cursor, block_sums, ticket, rec, aux, total;
+    int n_keys, n_scan_blocks;
+    long long cap;
+};
+
+static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int s1, int s2, Layout &L,
+                        int &nt0, int &nt1, int &nt2)
+{
+    nt0 = (g->size0 + (1 << s0) - 1) >> s0;
+    nt1 = (g->size1 + (1 << s1) - 1) >> s1;
+    nt2 = (g->size2 + (1 << s2) - 1) >> s2;
+    const long long n_keys = (long long)nt0 * nt1 * nt2 * G;
+    const long long cap = n_points * 8;
+    if (n_keys + 1 > 0x7fffff00LL || cap > 0x7fffff00LL) return false;
+    L.n_keys = (int)n_keys;
+    L.cap = cap;
+    L.n_scan_blocks = (int)((n_keys + 1 + SCAN_TILE - 1) / SCAN_TILE);
+    size_t off = 0;
+    L.cursor = off; off = align_up(off + (size_t)(n_keys + 1) * 4, 256);
+    L.block_sums = off; off = align_up(off + (size_t)L.n_scan_blocks * 4, 256);
+    L.ticket = off; off = align_up(off + 256, 256);
+    L.rec = off; off = align_up(off + (size_t)cap * 16, 256);
+    L.aux = off; off = align_up(off + (size_t)cap * 4, 256);
+    L.total = off;
+    return true;
+}
+
+static int check_grid(const mf_grid *g, bool need_bins)
+{
+    if (!g) return fail(MF_ERR_INVALID, "grid is NULL");
+    if (g->size0 < 1 || g->size1 < 1 || g->size2 < 1 || g->size0 > 1024 || g->size1 > 1024 || g->size2 > 1024)
+        return fail(MF_ERR_INVALID, "map dims must be in [1, 1024], got %d x %d x %d", g->size0, g->size1, g->size2);
+    if (g->channels < 1 || g->channels > 8192)
+        return fail(MF_ERR_INVALID, "channels must be in [1, 8192], got %d", g->channels);
+    if (!g->map) return fail(MF_ERR_INVALID, "grid->map is NULL");
+    if (need_bins) {
+        if (!g->bins_x || !g->bins_y || !g->bins_z) return fail(MF_ERR_INVALID, "bin edge pointer is NULL");
+        if (g->n_edges_x != g->size1 + 1 || g->n_edges_y != g->size0 + 1 || g->n_edges_z != g->size2 + 1)
+            return fail(MF_ERR_INVALID, "edge counts (%d, %d, %d) must be (size1+1, size0+1, size2+1) = (%d, %d, %d)",
+                        g->n_edges_x, g->n_edges_y, g->n_edges_z, g->size1 + 1, g->size0 + 1, g->size2 + 1);
+    }
+    return MF_OK;
+}
+
+static int check_frames(const mf_frames *f, int C)
+{
+    if (!f) return fail(MF_ERR_INVALID, "frames is NULL");
+    if (f->n_frames < 1 || f->height < 1 || f->width < 1)
+        return fail(MF_ERR_INVALID, "n_frames/height/width must be positive");
+    if (!f->cam_rays || !f->poses || !f->depth) return fail(MF_ERR_INVALID, "cam_rays/poses/depth pointer is NULL");
+    if (f->feat_kind < MF_FEAT_ONES || f->feat_kind > MF_FEAT_DENSE_F32)
+        return fail(MF_ERR_INVALID, "unknown feat_kind %d", f->feat_kind);
+    if (f->feat_kind == MF_FEAT_ONES) {
+        if (C != 1) return fail(MF_ERR_INVALID, "MF_FEAT_ONES needs channels == 1, got %d", C);
+    } else {
+        if (!f->feat) return fail(MF_ERR_INVALID, "feat pointer is NULL");
+        if (f->feat_height < 1 || f->feat_width < 1 || f->height % f->feat_height || f->width % f->feat_width)
+            return fail(MF_ERR_INVALID, "feature resolution %dx%d must divide the camera resolution %dx%d",
+                        f->feat_height, f->feat_width, f->height, f->width);
+    }
+    return MF_OK;
+}
+
+static void fill_grid(FuseParams &P, const mf_grid *g)
+{
+    P.size0 = g->size0; P.size1 = g->size1; P.size2 = g->size2; P.C = g->channels;
+    P.bins.b0 = g->bins_x; P.bins.b1 = g->bins_y; P.bins.b2 = g->bins_z;
+    P.bins.n0 = g->n_edges_x; P.bins.n1 = g->n_edges_y; P.bins.n2 = g->n_edges_z;
+    P.map = g->map;
+    P.magicC = g->channels == 1 ? 0u : (unsigned)(((1ull << 32) + g->channels - 1) / g->channels);
+}
+
+static void fill_frames(FuseParams &P, const mf_frames *f)
+{
+    P.n_frames = f->n_frames; P.H = f->height; P.W = f->width;
+    P.cam = f->cam_rays; P.poses = f->poses; P.depth = f->depth; P.feat = f->feat;
+    P.feat_kind = f->feat_kind;
+    P.fh = f->feat_kind == MF_FEAT_ONES ? f->height : f->feat_height;
+    P.fw = f->feat_kind == MF_FEAT_ONES ? f->width : f->feat_width;
+    P.rep_y = f->height / P.fh; P.rep_x = f->width / P.fw;
+    P.min_d = f->min_depth; P.max_d = f->max_depth;
+    P.n_points = (long long)f->n_frames * f->height * f->width;
+}
+
+template <int FRONT>
+static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, size_t workspace_bytes, hipStream_t st)
+{
+    if (P.G < 1 || P.G > MAX_GROUPS)
+        return fail(MF_ERR_INVALID, "at most %d sequential frames per call, got %d", MAX_GROUPS, P.G);
+    if (P.n_points == 0) return MF_OK;
+    choose_tile(grid, P.s0, P.s1, P.s2);
+    Layout L;
+    if (!make_layout(grid, P.n_points, P.G, P.s0, P.s1, P.s2, L, P.nt0, P.nt1, P.nt2))
+        return fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets (points %lld, groups %d)",
+                    P.n_points, P.G);
+    if (!workspace || workspace_bytes < L.total)
+        return fail(MF_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, L.total);
+    if (((uintptr_t)workspace & 255) != 0) return fail(MF_ERR_INVALID, "workspace must be 256-byte aligned");
+    char *ws = (char *)workspace;
+    P.cursor = (int *)(ws + L.cursor);
+    P.block_sums = (int *)(ws + L.block_sums);
+    P.ticket = (int *)(ws + L.ticket);
+    P.rec = (uint4 *)(ws + L.rec);
+    P.aux = (uint32_t *)(ws + L.aux);
+    P.n_tiles = P.nt0 * P.nt1 * P.nt2;
+    P.n_keys = L.n_keys;
+
+    // cursor .. ticket are contiguous: one memset
+    MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, L.rec - L.cursor, st));
+    const unsigned bin_blocks = (unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS);
+    hipLaunchKernelGGL(count_kernel<FRONT>, dim3(bin_blocks), dim3(BIN_THREADS), 0, st, P);
+    MF_LAUNCH_CHECK("count_kernel");
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
+                       (const int *)P.cursor, P.n_keys + 1, P.block_sums);
+    MF_LAUNCH_CHECK("scan_sums_kernel");
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
+                       P.cursor, P.n_keys + 1, (const int *)P.block_sums);
+    MF_LAUNCH_CHECK("scan_apply_kernel");
+    hipLaunchKernelGGL(scatter_kernel<FRONT>, dim3(bin_blocks), dim3(BIN_THREADS), 0, st, P);
+    MF_LAUNCH_CHECK("scatter_kernel");
+
+    const int sv = P.s0 + P.s1 + P.s2;
+    const size_t lds = tile_lds_bytes(P.C, sv);
+    const DeviceInfo &dev = device_info();
+    if (lds > (size_t)dev.lds_per_cu)
+        return fail(MF_ERR_INVALID, "tile needs %zu bytes of LDS, device has %d", lds, dev.lds_per_cu);
+    const int nt = ((size_t)(1 << sv) * P.C >= 8192) ? 1024 : 256;
+    int per_cu = (int)((size_t)dev.lds_per_cu / lds);
+    const int by_threads = 2048 / nt;
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu < 1) per_cu = 1;
+    int blocks = dev.cus * per_cu;
+    if (blocks > P.n_tiles) blocks = P.n_tiles;
+    const int kind = P.feat_kind == MF_FEAT_ONES ? 0 : (P.feat_kind == MF_FEAT_DENSE_F32 ? 2 : 1);
+    void (*kern)(FuseParams) = kind == 0 ? fuse_tiles_kernel<0> : kind == 1 ? fuse_tiles_kernel<1> : fuse_tiles_kernel<2>;
+    MF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, P);
+    MF_LAUNCH_CHECK("fuse_tiles_kernel");
+    return MF_OK;
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" {
+
+size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int32_t n_groups)
+{
+    if (check_grid(grid, false) != MF_OK) return 0;
+    if (n_points < 0 || n_groups < 1 || n_groups > MAX_GROUPS) {
+        fail(MF_ERR_INVALID, "n_points must be >= 0 and n_groups in [1, %d]", MAX_GROUPS);
+        return 0;
+    }
+    int s0, s1, s2, a, b, c;
+    choose_tile(grid, s0, s1, s2);
+    Layout L;
+    if (!make_layout(grid, n_points, n_groups, s0, s1, s2, L, a, b, c)) {
+        fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets");
+        return 0;
+    }
+    return L.total;
+}
+
+int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight, int32_t mode,
+                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_grid(grid, true);
+    if (rc != MF_OK) return rc;
+    rc = check_frames(frames, grid->channels);
+    if (rc != MF_OK) return rc;
+    if (mode != MF_MODE_SEQUENTIAL && mode != MF_MODE_MERGED) return fail(MF_ERR_INVALID, "unknown mode %d", mode);
+    FuseParams P = {};
+    fill_grid(P, grid);
+    fill_frames(P, frames);
+    P.G = mode == MF_MODE_SEQUENTIAL ? frames->n_frames : 1;
+    P.iw = interpolation_weight;
+    return run_pipeline<0>(P, grid, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mf_update_feature_map(const mf_grid *grid, int64_t n, const int64_t *ind0, const int64_t *ind1,
+                          const int64_t *ind2, const float *ratio0, const float *ratio1, const float *ratio2,
+                          const void *feat, int32_t feat_kind, float interpolation_weight, void *workspace,
+                          size_t workspace_bytes, void *stream)
+{
+    int rc = check_grid(grid, false);
+    if (rc != MF_OK) return rc;
+    if (n < 0) return fail(MF_ERR_INVALID, "n must be >= 0");
+    if (n == 0) return MF_OK;
+    if (!ind0 || !ind1 || !ind2 || !ratio0 || !ratio1 || !ratio2) return fail(MF_ERR_INVALID, "index/ratio pointer is NULL");
+    if (feat_kind < MF_FEAT_ONES || feat_kind > MF_FEAT_DENSE_F32) return fail(MF_ERR_INVALID, "unknown feat_kind %d", feat_kind);
+    if (feat_kind == MF_FEAT_ONES && grid->channels != 1) return fail(MF_ERR_INVALID, "MF_FEAT_ONES needs channels == 1");
+    if (feat_kind != MF_FEAT_ONES && !feat) return fail(MF_ERR_INVALID, "feat pointer is NULL");
+    FuseParams P = {};
+    fill_grid(P, grid);
+    P.i0 = ind0; P.i1 = ind1; P.i2 = ind2; P.q0 = ratio0; P.q1 = ratio1; P.q2 = ratio2;
+    P.feat = feat; P.feat_kind = feat_kind;
+    P.n_points = n; P.G = 1; P.iw = interpolation_weight;
+    return run_pipeline<1>(P, grid, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mf_transform_rays(const float *cam_rays, int64_t n_pixels, const float *poses, int32_t n_frames, float *out,
+                      void *stream)
+{
+    if (!cam_rays || !poses || !out || n_pixels < 0 || n_frames < 0) return fail(MF_ERR_INVALID, "bad argument");
+    const long long n = n_pixels * n_frames;
+    if (n == 0) return MF_OK;
+    hipLaunchKernelGGL(transform_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       cam_rays, (long long)n_pixels, poses, n_frames, out);
+    MF_LAUNCH_CHECK("transform_rays_kernel");
+    return MF_OK;
+}
+
+int mf_bin_rays(const float *bins0, int32_t n0, const float *bins1, int32_t n1, const float *bins2, int32_t n2,
+                const float *origin, const float *rays, int32_t rays_per_frame, const float *depth,
+                int32_t n_frames, int64_t n_pixels, float min_depth, float max_depth, int64_t *ind0, int64_t *ind1,
+                int64_t *ind2, float *ratio0, float *ratio1, float *ratio2, uint8_t *valid, void *stream)
+{
+    if (!bins0 || !bins1 || !bins2 || n0 < 2 || n1 < 2 || n2 < 2) return fail(MF_ERR_INVALID, "each axis needs >= 2 bin edges");
+    if (!origin || !rays || !depth || n_frames < 0 || n_pixels < 0) return fail(MF_ERR_INVALID, "bad argument");
+    const long long n = (long long)n_pixels * n_frames;
+    if (n == 0) return MF_OK;
+    Bins B = {bins0, bins1, bins2, n0, n1, n2};
+    BinOut o = {ind0, ind1, ind2, ratio0, ratio1, ratio2, valid};
+    hipLaunchKernelGGL(bin_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B,
+                       origin, rays, rays_per_frame, depth, n_frames, (long long)n_pixels, min_depth, max_depth, o);
+    MF_LAUNCH_CHECK("bin_rays_kernel");
+    return MF_OK;
+}
+
+int mf_unproject_bin(const mf_grid *grid, const mf_frames *frames, int64_t *ind_x, int64_t *ind_y, int64_t *ind_z,
+                     float *ratio_x, float *ratio_y, float *ratio_z, uint8_t *valid, void *stream)
+{
+    int rc = check_grid(grid, true);
+    if (rc != MF_OK) return rc;
+    if (!frames || !frames->cam_rays || !frames->poses || !frames->depth || frames->n_frames < 1)
+        return fail(MF_ERR_INVALID, "frames incomplete");
+    FuseParams P = {};
+    fill_grid(P, grid);
+    mf_frames f = *frames;
+    f.feat_kind = MF_FEAT_ONES;
+    fill_frames(P, &f);
+    P.G = 1;
+    BinOut o = {ind_x, ind_y, ind_z, ratio_x, ratio_y, ratio_z, valid};
+    hipLaunchKernelGGL(unproject_bin_kernel, dim3((unsigned)((P.n_points + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, P, o);
+    MF_LAUNCH_CHECK("unproject_bin_kernel");
+    return MF_OK;
+}
+
+}  // extern "C"

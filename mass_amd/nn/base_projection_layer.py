@@ -1,0 +1,188 @@
+"""BaseProjectionLayer — the voxel feature map and its per-frame update.
+
+Mirrors /root/reference/mass/nn/base_projection_layer.py (class at :15): same
+constructor kwargs, same buffers (``rays``, ``data``, ``bins_x/y/z``), same
+method names and return conventions, so callers such as the reference's
+agent.py / navigation_policy.py can use it unchanged.  ``update`` runs the
+fused HIP pipeline (mass_amd.utils.projection.fuse_frames) instead of the
+reference's ~40 torch ops; the coordinate helpers are plain torch.
+"""
+from typing import Any, Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as functional
+
+from mass_amd.nn.projection_layer import ProjectionLayer
+from mass_amd.utils.projection import (project_camera_rays, spherical_to_cartesian, pack_poses,
+                                       fuse_frames, Workspace)
+
+
+def _edges(origin, cells, resolution):
+    """cells + 1 bin edges centred on origin (base_projection_layer.py:164-181).
+    The values are whatever torch.arange produces on the host; they are data."""
+    lo = origin - (cells + 1) * resolution / 2
+    hi = origin + (cells + 1) * resolution / 2 - 1e-6
+    return torch.arange(lo, hi, resolution, dtype=torch.float32)
+
+
+class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
+
+    def __init__(self, camera_height: int = 224, camera_width: int = 224,
+                 vertical_fov: float = 90.0, map_height: int = 256,
+                 map_width: int = 256, map_depth: int = 64,
+                 feature_size: int = 1, dtype: torch.dtype = torch.float32,
+                 origin_y: float = 0.0, origin_x: float = 0.0,
+                 origin_z: float = 0.0, grid_resolution: float = 0.05,
+                 interpolation_weight: float = 0.5,
+                 initial_feature_map: torch.Tensor = None):
+        super(BaseProjectionLayer, self).__init__()
+        if dtype != torch.float32:
+            raise NotImplementedError("the HIP map update is float32 only")
+        self.interpolation_weight = interpolation_weight
+        self.camera_height, self.camera_width = camera_height, camera_width
+        self.vertical_fov = vertical_fov
+        self.map_height, self.map_width, self.map_depth = map_height, map_width, map_depth
+        self.feature_size = feature_size
+        self.origin_x, self.origin_y, self.origin_z = origin_x, origin_y, origin_z
+        self.grid_resolution = grid_resolution
+
+        # pinhole rays, one per pixel (base_projection_layer.py:151-154)
+        focal_length = camera_height / 2.0 / np.tan(np.radians(vertical_fov) / 2.0)
+        self.register_buffer('rays', project_camera_rays(
+            camera_height, camera_width, focal_length, focal_length))
+        self.register_buffer('data', torch.zeros(
+            map_height, map_width, map_depth, feature_size, dtype=dtype)
+            if initial_feature_map is None else initial_feature_map)
+        self.register_buffer('bins_x', _edges(origin_x, map_width, grid_resolution))
+        self.register_buffer('bins_y', _edges(origin_y, map_height, grid_resolution))
+        self.register_buffer('bins_z', _edges(origin_z, map_depth, grid_resolution))
+        self._workspace = Workspace()
+
+    # ------------------------------------------------------------------ state
+    def reset(self, origin_y: float = 0.0, origin_x: float = 0.0, origin_z: float = 0.0):
+        """Zero the map and re-centre the bin edges (base_projection_layer.py:183-235)."""
+        self.origin_x, self.origin_y, self.origin_z = origin_x, origin_y, origin_z
+        self.data.zero_()
+        self.bins_x.copy_(_edges(origin_x, self.map_width, self.grid_resolution))
+        self.bins_y.copy_(_edges(origin_y, self.map_height, self.grid_resolution))
+        self.bins_z.copy_(_edges(origin_z, self.map_depth, self.grid_resolution))
+
+    def get_feature_map(self):
+        return self.data
+
+    def forward(self, observation: Dict[str, torch.Tensor]):
+        self.update(observation)
+        return self.get_feature_map()
+
+    # ----------------------------------------------------------------- update
+    def _poses(self, position, yaw, elevation):
+        """Host-side pose math with the reference's torch ops on the CPU
+        (projection.py:29-31,104-105; base_projection_layer.py:330-331), so the
+        device never evaluates sin/cos and the rotation is bit-identical to the
+        reference CPU path.  Returns device [B, 12]."""
+        position = torch.as_tensor(position, dtype=torch.float32, device='cpu').reshape(-1, 3)
+        yaw = torch.as_tensor(yaw, dtype=torch.float32, device='cpu').reshape(-1)
+        elevation = torch.as_tensor(elevation, dtype=torch.float32, device='cpu').reshape(-1)
+        eye = spherical_to_cartesian(yaw, elevation)
+        up = spherical_to_cartesian(yaw, elevation + np.pi / 2)
+        return pack_poses(position, eye, up).to(self.data.device, non_blocking=True)
+
+    def _splat(self, position, yaw, elevation, depth, features, sequential=True):
+        depth = torch.as_tensor(depth, dtype=torch.float32, device=self.data.device)
+        fuse_frames(self.bins_x, self.bins_y, self.bins_z, self.rays,
+                    self._poses(position, yaw, elevation), depth, features, self.data,
+                    interpolation_weight=self.interpolation_weight, sequential=sequential,
+                    workspace=self._workspace)
+
+    def update(self, observation: Dict[str, torch.Tensor]):
+        """Project one posed depth + feature frame onto the map, in place
+        (base_projection_layer.py:282-343).  Keys: position [3], yaw, elevation
+        (radians), depth [H, W, 1] metres, features [h, w, C] with h | H, w | W."""
+        features = torch.as_tensor(observation["features"], dtype=self.data.dtype,
+                                   device=self.data.device)
+        self._splat(observation["position"], observation["yaw"], observation["elevation"],
+                    observation["depth"], features)
+        return self
+
+    def update_batch(self, observation: Dict[str, torch.Tensor], sequential: bool = True):
+        """Extension: a leading batch of frames in one call.  sequential=True is
+        exactly B successive update() calls (what agent.py does frame by frame);
+        False is the functional API's merged point set."""
+        features = observation.get("features")
+        if features is not None:
+            features = torch.as_tensor(features, device=self.data.device)
+            if features.is_floating_point():
+                features = features.to(self.data.dtype)
+        self._splat(observation["position"], observation["yaw"], observation["elevation"],
+                    observation["depth"], features, sequential=sequential)
+        return self
+
+    # ------------------------------------------------- reductions / transforms
+    def top_down(self, depth_slice: slice = slice(0, 32)):
+        """Feature vector of the highest occupied voxel of every (y, x) column
+        (base_projection_layer.py:345-379)."""
+        fm = self.data[:, :, depth_slice] if depth_slice is not None else self.data
+        mask = torch.ne(fm, 0).any(dim=-1, keepdim=True).to(dtype=fm.dtype)
+        idx = (mask.cumsum(dim=-2) * mask).argmax(dim=-2, keepdim=True)
+        shape = list(fm.shape[:-2]) + [1, fm.shape[-1]]
+        return torch.gather(fm, -2, idx.expand(*shape)).squeeze(-2)
+
+    def clamp_to_world(self, coords):
+        """Clamp xyz world coordinates to the centres of the outermost voxels
+        (base_projection_layer.py:381-416)."""
+        coords = torch.as_tensor(coords, dtype=torch.float32, device=self.data.device)
+        upper = torch.stack([(self.bins_x[-1] + self.bins_x[-2]) / 2,
+                             (self.bins_y[-1] + self.bins_y[-2]) / 2,
+                             (self.bins_z[-1] + self.bins_z[-2]) / 2])
+        lower = torch.stack([(self.bins_x[0] + self.bins_x[1]) / 2,
+                             (self.bins_y[0] + self.bins_y[1]) / 2,
+                             (self.bins_z[0] + self.bins_z[1]) / 2])
+        shape = [1 for _ in coords.shape[:-1]] + [3]
+        return coords.clamp(min=lower.view(*shape)[..., :coords.shape[-1]],
+                            max=upper.view(*shape)[..., :coords.shape[-1]])
+
+    def clamp_to_map(self, coords):
+        """Clamp xyz map coordinates to [0, size - 1] (base_projection_layer.py:418-450)."""
+        kwargs = dict(dtype=coords.dtype, device=self.data.device)
+        coords = torch.as_tensor(coords, **kwargs)
+        lower = torch.tensor([0, 0, 0], **kwargs)
+        upper = torch.tensor([self.map_width - 1, self.map_height - 1, self.map_depth - 1], **kwargs)
+        shape = [1 for _ in coords.shape[:-1]] + [3]
+        return coords.clamp(min=lower[:coords.shape[-1]].view(*shape),
+                            max=upper[:coords.shape[-1]].view(*shape))
+
+    def map_to_world(self, coords):
+        """xyz map coordinates -> world coordinates by interpolating between
+        voxel centres; the y axis is stored flipped (base_projection_layer.py:452-511)."""
+        coords = self.clamp_to_map(coords).to(dtype=torch.float32)
+        floored = coords.floor()
+        idx = floored.to(dtype=torch.int64)
+        centres = [((self.bins_x[:-1] + self.bins_x[1:]).view(-1, 1) / 2, self.map_width),
+                   ((self.bins_y[:-1] + self.bins_y[1:]).flip(-1).view(-1, 1) / 2, self.map_height)]
+        if coords.shape[-1] == 3:
+            centres.append(((self.bins_z[:-1] + self.bins_z[1:]).view(-1, 1) / 2, self.map_depth))
+        left, right = [], []
+        for axis, (table, size) in enumerate(centres):
+            left.append(functional.embedding(idx[..., axis], table))
+            right.append(functional.embedding((idx[..., axis] + 1).clamp(min=0, max=size - 1), table))
+        left, right = torch.cat(left, dim=-1), torch.cat(right, dim=-1)
+        return left + (right - left) * (coords - floored)
+
+    def world_to_map(self, coords):
+        """xyz world coordinates -> integer voxel coordinates (xyz order), y
+        flipped consistently with the update (base_projection_layer.py:513-547)."""
+        coords = self.clamp_to_world(coords)
+        bins = [torch.bucketize(coords[..., 0].contiguous(), self.bins_x, right=True) - 1,
+                self.bins_y.size(dim=0) -
+                torch.bucketize(coords[..., 1].contiguous(), self.bins_y, right=True) - 1]
+        if coords.shape[-1] == 3:
+            bins.append(torch.bucketize(coords[..., 2].contiguous(), self.bins_z, right=True) - 1)
+        return torch.stack(bins, dim=-1)
+
+    def visualize(self, obs: Dict[str, Any], depth_slice: slice = slice(0, 32)):
+        """Free-space image: 1 where no voxel of the column slice is occupied
+        (base_projection_layer.py:549-578)."""
+        fm = self.data[:, :, depth_slice] if depth_slice is not None else self.data
+        occupied = torch.ne(fm, 0).any(dim=-1, keepdim=True).to(dtype=torch.float32)
+        return 1.0 - np.tile(occupied.detach().cpu().numpy(), (1, 1, 3))

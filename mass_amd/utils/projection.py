@@ -1,0 +1,285 @@
+"""Functional API of the map update, mirroring the reference's
+``mass.utils.projection`` (/root/reference/mass/utils/projection.py) name for
+name and argument for argument:
+
+    spherical_to_cartesian   projection.py:6-31     host torch ops (O(1) pose math)
+    project_camera_rays      projection.py:34-74    host torch ops (once per layer)
+    transform_rays           projection.py:77-110   HIP  mf_transform_rays
+    bin_rays                 projection.py:113-230  HIP  mf_bin_rays (+ torch compaction)
+    update_feature_map       projection.py:233-351  HIP  mf_update_feature_map
+
+The per-pixel and per-voxel work runs in libmassfuse.so; tensors must live on
+a HIP device (no CPU fallback).  ``fuse_frames`` is the fused entry the layers
+use (transform + bin + update in one pipeline, nothing materialised).
+"""
+import numpy as np
+import torch
+
+from mass_amd import _lib
+from mass_amd._lib import lib, check, ptr, require_device, current_stream
+
+
+def spherical_to_cartesian(yaw, elevation):
+    """Unit vector for a yaw / elevation pair (projection.py:29-31)."""
+    return torch.stack([torch.cos(yaw) * torch.cos(elevation),
+                        torch.sin(yaw) * torch.cos(elevation),
+                        torch.sin(elevation)], dim=-1)
+
+
+def project_camera_rays(image_height, image_width, focal_length_y, focal_length_x,
+                        dtype=torch.float32, device='cpu'):
+    """Camera-frame ray per pixel, (rx, -ry, -1) (projection.py:67-74)."""
+    kwargs = dict(dtype=dtype, device=device)
+    y, x = torch.meshgrid(torch.arange(image_height, **kwargs),
+                          torch.arange(image_width, **kwargs), indexing='ij')
+    rays_y = (y - 0.5 * float(image_height - 1)) / focal_length_y
+    rays_x = (x - 0.5 * float(image_width - 1)) / focal_length_x
+    return torch.stack([rays_x, -rays_y, -torch.ones_like(rays_x)], dim=-1)
+
+
+def rotation_matrix(eye_vector, up_vector):
+    """R = stack([eye x up, up, -eye], dim=-1) (projection.py:104-105); the
+    cross product is taken over the last axis (the reference's dim-less
+    torch.cross would pick axis 0 for a batch of exactly three poses)."""
+    return torch.stack([torch.linalg.cross(eye_vector, up_vector, dim=-1),
+                        up_vector, -eye_vector], dim=-1)
+
+
+def pack_poses(origin, eye_vector, up_vector):
+    """[..., 12] fp32 pose rows (origin[3], R[3][3] row-major) for the C ABI."""
+    R = rotation_matrix(eye_vector, up_vector)
+    return torch.cat([origin.to(torch.float32), R.reshape(*R.shape[:-2], 9).to(torch.float32)], dim=-1)
+
+
+def _f32c(t):
+    return t.to(torch.float32).contiguous()
+
+
+def transform_rays(rays, eye_vector, up_vector):
+    """Camera rays [..., H, W, 3] -> world rays (projection.py:77-110).
+
+    ``rays`` may carry a leading batch that matches ``eye_vector`` [B, 3]; the
+    same camera rays for every pose is the common case and is not expanded."""
+    require_device(rays, eye_vector, up_vector)
+    batched = eye_vector.dim() == 2
+    eye = eye_vector if batched else eye_vector.unsqueeze(0)
+    up = up_vector if batched else up_vector.unsqueeze(0)
+    n_frames = eye.shape[0]
+    poses = _f32c(pack_poses(torch.zeros_like(eye), eye, up))
+    stream = current_stream(rays.device)
+    if batched and rays.dim() == 4 and rays.shape[0] == n_frames and n_frames > 1:
+        outs = [transform_rays(rays[b], eye[b], up[b]) for b in range(n_frames)]
+        return torch.stack(outs, dim=0)
+    cam = _f32c(rays[0] if (batched and rays.dim() == 4) else rays)
+    n_pix = cam.numel() // 3
+    out = torch.empty((n_frames,) + tuple(cam.shape), dtype=torch.float32, device=cam.device)
+    check(lib.mf_transform_rays(ptr(cam), n_pix, ptr(poses), n_frames, ptr(out), stream))
+    return out if batched else out[0]
+
+
+def bin_rays_dense(bins0, bins1, bins2, origin, rays, depth, min_ray_depth=0.0, max_ray_depth=10.0):
+    """Uncompacted bin_rays: (ind0, ind1, ind2, ratio0, ratio1, ratio2, valid)
+    shaped like ``depth`` without its last axis."""
+    require_device(bins0, bins1, bins2, origin, rays, depth)
+    depth = _f32c(depth)
+    lead = depth.shape[:-1]
+    if origin.dim() == 1:
+        n_frames, o = 1, _f32c(origin.unsqueeze(0))
+    else:
+        n_frames, o = origin.shape[0], _f32c(origin)
+        if lead[0] != n_frames:
+            raise ValueError("origin batch does not match depth batch")
+    n_pix = depth.numel() // n_frames
+    per_frame = int(rays.numel() == depth.numel() * 3)
+    if not per_frame and rays.numel() != n_pix * 3:
+        raise ValueError("rays must have one 3-vector per depth pixel")
+    rays = _f32c(rays)
+    b0, b1, b2 = _f32c(bins0), _f32c(bins1), _f32c(bins2)
+    dev = depth.device
+    ind = [torch.empty(lead, dtype=torch.int64, device=dev) for _ in range(3)]
+    rat = [torch.empty(lead, dtype=torch.float32, device=dev) for _ in range(3)]
+    valid = torch.empty(lead, dtype=torch.uint8, device=dev)
+    check(lib.mf_bin_rays(ptr(b0), b0.numel(), ptr(b1), b1.numel(), ptr(b2), b2.numel(),
+                          ptr(o), ptr(rays), per_frame, ptr(depth), n_frames, n_pix,
+                          float(min_ray_depth), float(max_ray_depth),
+                          ptr(ind[0]), ptr(ind[1]), ptr(ind[2]), ptr(rat[0]), ptr(rat[1]), ptr(rat[2]),
+                          ptr(valid), current_stream(dev)))
+    return (*ind, *rat, valid)
+
+
+def bin_rays(bins0, bins1, bins2, origin, rays, depth,
+             *features, min_ray_depth=0.0, max_ray_depth=10.0):
+    """Voxel index / in-voxel ratio of every valid ray end point, compacted in
+    row-major pixel order, plus the matching feature rows (projection.py:113-230)."""
+    i0, i1, i2, r0, r1, r2, valid = bin_rays_dense(bins0, bins1, bins2, origin, rays, depth,
+                                                   min_ray_depth=min_ray_depth,
+                                                   max_ray_depth=max_ray_depth)
+    indices = torch.nonzero(valid, as_tuple=True)
+    return (i0[indices], i1[indices], i2[indices], r0[indices], r1[indices], r2[indices],
+            *[features_i[indices] for features_i in features])
+
+
+class Workspace:
+    """Grow-only device scratch for the fuse pipeline (owned by the caller,
+    as the C ABI requires)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        base = self.buf.data_ptr()
+        return _lib.c_void_p((base + 255) // 256 * 256), self.buf.numel() - 256
+
+
+_default_workspace = Workspace()
+
+
+def _grid_struct(feature_map, bins_x=None, bins_y=None, bins_z=None):
+    s0, s1, s2, C = feature_map.shape[-4:]
+    g = _lib.MfGrid()
+    g.size0, g.size1, g.size2, g.channels = s0, s1, s2, C
+    if bins_x is not None:
+        g.bins_x, g.bins_y, g.bins_z = bins_x.data_ptr(), bins_y.data_ptr(), bins_z.data_ptr()
+        g.n_edges_x, g.n_edges_y, g.n_edges_z = bins_x.numel(), bins_y.numel(), bins_z.numel()
+    g.map = feature_map.data_ptr()
+    return g
+
+
+def _feature_kind(features, C):
+    """(kind, tensor) for a per-point / per-pixel feature tensor."""
+    if features is None:
+        return _lib.FEAT_ONES, None
+    if features.dtype == torch.uint8:
+        return _lib.FEAT_LABEL_U8, features.contiguous()
+    if features.dtype == torch.int32:
+        return _lib.FEAT_LABEL_I32, features.contiguous()
+    if features.dtype == torch.int64:
+        return _lib.FEAT_LABEL_I64, features.contiguous()
+    return _lib.FEAT_DENSE_F32, _f32c(features)
+
+
+def _check_map(feature_map):
+    require_device(feature_map)
+    if feature_map.dtype != torch.float32 or not feature_map.is_contiguous():
+        raise ValueError("feature_map must be a contiguous float32 tensor")
+    if feature_map.dim() == 5 and feature_map.shape[0] == 1:
+        feature_map = feature_map[0]
+    if feature_map.dim() != 4:
+        raise NotImplementedError("a leading batch of maps is not supported (unused by the reference's callers)")
+    return feature_map
+
+
+def update_feature_map(ind0, ind1, ind2, ratio0, ratio1, ratio2,
+                       features, feature_map, interpolation_weight=1.0, workspace=None):
+    """Trilinear 8-corner normalised-blend splat of ``features`` [n, C] into
+    ``feature_map`` [size0, size1, size2, C], in place (projection.py:233-351).
+
+    Extension: an integer ``features`` tensor [n] is taken as class ids and
+    stands for one_hot(features, C).float() without materialising it."""
+    fm = _check_map(feature_map)
+    require_device(ind0, ind1, ind2, ratio0, ratio1, ratio2, features)
+    C = fm.shape[-1]
+    n = ind0.numel()
+    if n == 0:
+        return
+    kind, feat = _feature_kind(features, C)
+    if kind == _lib.FEAT_DENSE_F32:
+        feat = feat.reshape(-1, C)
+        if feat.shape[0] != n:
+            raise ValueError("features must have one row per point")
+    elif kind != _lib.FEAT_ONES and feat.numel() != n:
+        raise ValueError("label features must have one id per point")
+    i0, i1, i2 = (t.reshape(-1).to(torch.int64).contiguous() for t in (ind0, ind1, ind2))
+    r0, r1, r2 = (_f32c(t.reshape(-1)) for t in (ratio0, ratio1, ratio2))
+    g = _grid_struct(fm)
+    ws = workspace or _default_workspace
+    need = lib.mf_fuse_workspace_bytes(g, n, 1)
+    if need == 0:
+        check(_lib.MF_ERR_INVALID)
+    wptr, wbytes = ws.get(need, fm.device)
+    check(lib.mf_update_feature_map(g, n, ptr(i0), ptr(i1), ptr(i2), ptr(r0), ptr(r1), ptr(r2),
+                                    ptr(feat), kind, float(interpolation_weight), wptr, wbytes,
+                                    current_stream(fm.device)))
+
+
+def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map,
+                interpolation_weight=0.5, sequential=True, min_ray_depth=0.0, max_ray_depth=10.0,
+                workspace=None):
+    """transform_rays + bin_rays + update_feature_map for a batch of posed
+    frames in one fused pipeline (what BaseProjectionLayer.update runs).
+
+    cam_rays [H, W, 3]; poses [B, 12] (pack_poses); depth [B, H, W(, 1)];
+    features: None (ones, C == 1), integer class ids [B, h, w] or fp32
+    [B, h, w, C] with h | H and w | W.  sequential=True reproduces B successive
+    layer.update() calls, False the functional API's merged batch."""
+    fm = _check_map(feature_map)
+    require_device(bins_x, bins_y, bins_z, cam_rays, poses, depth, features)
+    H, W = cam_rays.shape[0], cam_rays.shape[1]
+    depth = _f32c(depth).reshape(-1, H, W)
+    B = depth.shape[0]
+    poses = _f32c(poses).reshape(-1, 12)
+    if poses.shape[0] != B:
+        raise ValueError("one pose row per frame expected")
+    C = fm.shape[-1]
+    kind, feat = _feature_kind(features, C)
+    fr = _lib.MfFrames()
+    fr.height, fr.width = H, W
+    cam = _f32c(cam_rays)
+    fr.cam_rays = cam.data_ptr()
+    fr.min_depth, fr.max_depth = float(min_ray_depth), float(max_ray_depth)
+    fr.feat_kind = kind
+    if kind == _lib.FEAT_DENSE_F32:
+        feat = feat.reshape(B, -1, feat.shape[-2], C) if feat.dim() >= 3 else feat
+        fr.feat_height, fr.feat_width = feat.shape[1], feat.shape[2]
+    elif kind != _lib.FEAT_ONES:
+        feat = feat.reshape(B, feat.shape[-2], feat.shape[-1])
+        fr.feat_height, fr.feat_width = feat.shape[1], feat.shape[2]
+    bx, by, bz = _f32c(bins_x), _f32c(bins_y), _f32c(bins_z)
+    g = _grid_struct(fm, bx, by, bz)
+    ws = workspace or _default_workspace
+    stream = current_stream(fm.device)
+    step = _lib.MAX_FRAMES_PER_CALL if sequential else B
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        fr.n_frames = nb
+        fr.poses = poses[b0:].data_ptr()
+        fr.depth = depth[b0:].data_ptr()
+        fr.feat = feat[b0:].data_ptr() if feat is not None else None
+        need = lib.mf_fuse_workspace_bytes(g, nb * H * W, nb if sequential else 1)
+        if need == 0:
+            check(_lib.MF_ERR_INVALID)
+        wptr, wbytes = ws.get(need, fm.device)
+        check(lib.mf_fuse_frames(g, fr, float(interpolation_weight),
+                                 _lib.MODE_SEQUENTIAL if sequential else _lib.MODE_MERGED,
+                                 wptr, wbytes, stream))
+
+
+def unproject_bin(bins_x, bins_y, bins_z, cam_rays, poses, depth, min_ray_depth=0.0, max_ray_depth=10.0):
+    """Fused transform_rays + bin_rays (uncompacted), in the (x, y, z) order of
+    bin_rays as BaseProjectionLayer.update calls it; parity/debug entry."""
+    require_device(bins_x, bins_y, bins_z, cam_rays, poses, depth)
+    H, W = cam_rays.shape[0], cam_rays.shape[1]
+    depth = _f32c(depth).reshape(-1, H, W)
+    B = depth.shape[0]
+    poses = _f32c(poses).reshape(B, 12)
+    cam = _f32c(cam_rays)
+    bx, by, bz = _f32c(bins_x), _f32c(bins_y), _f32c(bins_z)
+    dummy = torch.empty(1, dtype=torch.float32, device=depth.device)
+    g = _lib.MfGrid()
+    g.size0, g.size1, g.size2, g.channels = by.numel() - 1, bx.numel() - 1, bz.numel() - 1, 1
+    g.bins_x, g.bins_y, g.bins_z = bx.data_ptr(), by.data_ptr(), bz.data_ptr()
+    g.n_edges_x, g.n_edges_y, g.n_edges_z = bx.numel(), by.numel(), bz.numel()
+    g.map = dummy.data_ptr()
+    fr = _lib.MfFrames()
+    fr.n_frames, fr.height, fr.width = B, H, W
+    fr.cam_rays, fr.poses, fr.depth = cam.data_ptr(), poses.data_ptr(), depth.data_ptr()
+    fr.min_depth, fr.max_depth = float(min_ray_depth), float(max_ray_depth)
+    dev = depth.device
+    ind = [torch.empty((B, H, W), dtype=torch.int64, device=dev) for _ in range(3)]
+    rat = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(3)]
+    valid = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    check(lib.mf_unproject_bin(g, fr, ptr(ind[0]), ptr(ind[1]), ptr(ind[2]), ptr(rat[0]), ptr(rat[1]),
+                               ptr(rat[2]), ptr(valid), current_stream(dev)))
+    return (*ind, *rat, valid)

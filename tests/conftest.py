@@ -1,0 +1,68 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Fixtures are plain numpy archives: data only, no pickles."""
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def geom():
+    return load_golden("geom_small.npz")
+
+
+@pytest.fixture(scope="session")
+def splat():
+    return load_golden("splat_small.npz")
+
+
+@pytest.fixture(scope="session")
+def edge():
+    return load_golden("edge_cases.npz")
+
+
+@pytest.fixture(scope="session")
+def matchfx():
+    return load_golden("match_small.npz")
+
+
+@pytest.fixture(scope="session")
+def device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")
+
+
+# geometry of the small fixtures (tools/gen_golden.py)
+SMALL = dict(H=48, W=64, FOV=90.0, MAP=32, RES=0.1)
+POSE_OF_FRAME = (1, 2, 5)      # splat_small frames use geom poses 1, 2, 5
+
+
+def assert_map_close(got, want, rtol=1e-4, atol=1e-6, what="map"):
+    """North-star tolerance for fp32 feature sums: 1e-4 relative (+1e-6 abs
+    for values that are sums of ~1e-9 weights), and the occupancy pattern
+    (which entries are non-zero) must match exactly."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    occ_g, occ_w = got != 0, want != 0
+    assert np.array_equal(occ_g, occ_w), f"{what}: occupancy differs in {int((occ_g != occ_w).sum())} entries"
+    err = np.abs(got - want)
+    bound = rtol * np.abs(want) + atol
+    bad = err > bound
+    assert not bad.any(), (f"{what}: {int(bad.sum())} entries out of tolerance, "
+                           f"max abs err {err.max():.3e}, max rel {np.max(err / (np.abs(want) + 1e-30)):.3e}")

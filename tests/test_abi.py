@@ -1,0 +1,108 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol
+include/massfuse.h declares, validates arguments before touching the GPU, and
+its host-only entry (linear sum assignment) matches scipy."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from mass_amd import _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "massfuse.h")).read()
+    return re.findall(r"MF_API\s+[\w\s\*]+?\b(mf_\w+)\s*\(", text)
+
+
+def test_header_symbols_exported_and_bound():
+    names = declared_symbols()
+    assert len(names) >= 10 and len(set(names)) == len(names)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in massfuse.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in mass_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+
+
+def test_version_matches_header():
+    text = open(os.path.join(ROOT, "include", "massfuse.h")).read()
+    assert int(re.search(r"#define MF_ABI_VERSION (\d+)", text).group(1)) == _lib.lib.mf_version()
+
+
+def test_argument_validation_needs_no_gpu():
+    g = _lib.MfGrid()
+    assert _lib.lib.mf_fuse_workspace_bytes(g, 10, 1) == 0
+    assert b"map dims" in _lib.lib.mf_last_error()
+    g.size0 = g.size1 = g.size2 = 8
+    g.channels = 3
+    g.map = 256          # never dereferenced on the host
+    assert _lib.lib.mf_fuse_workspace_bytes(g, 100, 1) > 0
+    assert _lib.lib.mf_fuse_workspace_bytes(g, 100, 1000) == 0      # too many groups
+    rc = _lib.lib.mf_fuse_frames(g, None, 0.5, 0, None, 0, None)
+    assert rc == _lib.MF_ERR_INVALID
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+    assert _lib.lib.mf_pairwise_distance(None, 2, None, 2, 0, None, 0, None) == _lib.MF_ERR_INVALID
+    assert _lib.lib.mf_pairwise_distance(None, 0, None, 2, 4, None, 0, None) == _lib.MF_OK
+
+
+def test_operators_refuse_cpu_tensors():
+    import torch
+    from mass_amd.utils import projection as P
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.update_feature_map(torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int64),
+                             torch.zeros(1, dtype=torch.int64), torch.zeros(1), torch.zeros(1), torch.zeros(1),
+                             torch.zeros(1, 2), torch.zeros(4, 4, 4, 2))
+
+
+def lsa(cost):
+    cost = np.ascontiguousarray(cost, np.float64)
+    n0, n1 = cost.shape
+    k = min(n0, n1)
+    rows, cols = np.empty(k, np.int64), np.empty(k, np.int64)
+    n = _lib.check(_lib.lib.mf_linear_sum_assignment(cost.ctypes.data, n0, n1, rows.ctypes.data, cols.ctypes.data))
+    return rows[:n], cols[:n]
+
+
+def test_lsa_golden(matchfx):
+    tags = sorted({k[:-5] for k in matchfx.files if k.endswith("_rows")})
+    assert len(tags) >= 10
+    for t in tags:
+        cost = matchfx[t + "_cost"]
+        rows, cols = lsa(cost)
+        assert np.array_equal(rows, matchfx[t + "_rows"]), t
+        assert np.array_equal(cols, matchfx[t + "_cols"]), t
+
+
+def test_lsa_matches_scipy_random_and_ties():
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        n0, n1 = rng.integers(1, 12, 2)
+        if trial % 3 == 0:
+            cost = rng.integers(0, 4, (n0, n1)).astype(np.float64)      # many ties
+        elif trial % 3 == 1:
+            cost = rng.standard_normal((n0, n1))
+        else:
+            cost = rng.random((n0, n1)).astype(np.float32).astype(np.float64)
+            cost[rng.random((n0, n1)) < 0.1] = np.inf
+        try:
+            r, c = linear_sum_assignment(cost)
+        except ValueError:
+            with pytest.raises(ValueError):
+                lsa(cost)
+            continue
+        gr, gc = lsa(cost)
+        assert np.array_equal(gr, r) and np.array_equal(gc, c), (trial, cost)
+
+
+def test_lsa_rejects_nan_and_handles_empty():
+    with pytest.raises(ValueError):
+        lsa(np.array([[0.0, np.nan], [1.0, 2.0]]))
+    with pytest.raises(ValueError):
+        lsa(np.array([[0.0, -np.inf], [1.0, 2.0]]))
+    r, c = lsa(np.zeros((0, 3)))
+    assert r.size == 0 and c.size == 0

@@ -1,0 +1,171 @@
+"""BASELINE.json-size checks: 480x640 frames, 54 classes, 128^3 / 256^3 maps.
+Oracle comparisons where the oracle finishes in seconds, recorded reference
+digests, and size-independent properties (touched-set equality, batch ==
+repeated single updates, run-to-run agreement)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_map_close
+
+pytestmark = pytest.mark.gpu
+
+
+def config1_inputs():
+    g = torch.Generator().manual_seed(0)
+    depth = 0.5 + 2.5 * torch.rand(480, 640, 1, generator=g)
+    label = torch.randint(0, 54, (480, 640), generator=g)
+    return depth, label
+
+
+def semantic_layer(m, device, C=54, h=480, w=640, md=None):
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    return SemanticProjectionLayer(camera_height=h, camera_width=w, map_height=m, map_width=m, map_depth=md or m,
+                                   feature_size=C, grid_resolution=0.05).train().to(device)
+
+
+@pytest.mark.parametrize("m", [128, 256])
+def test_config1_digest_and_oracle(device, m):
+    """Same frame applied 3x (128^3) / 1x (256^3): reference digests + full oracle compare."""
+    from oracle import massref as orc
+    with open(os.path.join(GOLDEN, "digest_480x640.json")) as f:
+        ref = json.load(f)[f"map{m}"]
+    depth, label = config1_inputs()
+    rng_ok = hashlib.sha256(depth.numpy().tobytes()).hexdigest() == ref["depth_sha256"]
+    lay = semantic_layer(m, device)
+    ol = orc.RefProjectionLayer(camera_height=480, camera_width=640, map_height=m, map_width=m, map_depth=m,
+                                feature_size=54, grid_resolution=0.05)
+    obs = dict(position=np.asarray((0.1, -0.2, 0.3), np.float32), yaw=0.7, elevation=-0.5, depth=depth)
+    onehot = torch.nn.functional.one_hot(label, 54).float()
+    for rep in range(3 if m == 128 else 1):
+        lay.update(dict(obs, semantic=label[..., None]), validate=True)
+        ol.update(dict(obs, features=onehot))
+        got = lay.data.cpu()
+        assert_map_close(got.numpy(), ol.data.numpy(), what=f"rep {rep}")
+        if rng_ok:
+            want = ref[f"after_{rep + 1}"]
+            assert int((got != 0).any(-1).sum()) == want["occupied"]
+            assert int((got != 0).sum()) == want["nonzero"]
+            assert float(got.double().sum()) == pytest.approx(want["sum"], rel=1e-5)
+            assert float(got.max()) == pytest.approx(want["max"], rel=1e-4)
+            np.testing.assert_allclose(got.double().sum(dim=(0, 1, 2)).numpy(), want["channel_sums"], rtol=1e-4)
+    if rng_ok:
+        # bit-exact voxel indices: hash of the sorted flat ids of every valid point
+        from mass_amd.utils.projection import unproject_bin
+        ix, iy, iz, _, _, _, valid = unproject_bin(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays,
+                                                   lay._poses(obs["position"], 0.7, -0.5), depth.to(device))
+        v = valid.bool()
+        flat = ((iy[v] * m + ix[v]) * m + iz[v]).cpu().numpy().astype(np.int64)
+        assert flat.size == want["n_valid"]
+        assert hashlib.sha256(np.sort(flat).tobytes()).hexdigest() == want["sha256_sorted_flat_ids"]
+
+
+def dist_a_frames(n, seed0=0):
+    """SURVEY 8(d) config 2, distribution A: depth = 0.5 + 4.5 U, uniform labels,
+    pos ~ N(0, 0.3^2), yaw ~ U[0, 2pi), elevation ~ U[-0.6, 0]; one seed per frame."""
+    depth, label, pos, yaw, el = [], [], [], [], []
+    for s in range(seed0, seed0 + n):
+        g = torch.Generator().manual_seed(s)
+        depth.append(0.5 + 4.5 * torch.rand(480, 640, 1, generator=g))
+        label.append(torch.randint(0, 54, (480, 640), generator=g).to(torch.uint8))
+        pos.append(0.3 * torch.randn(3, generator=g))
+        yaw.append(2 * np.pi * torch.rand((), generator=g))
+        el.append(-0.6 * torch.rand((), generator=g))
+    return dict(position=torch.stack(pos), yaw=torch.stack(yaw), elevation=torch.stack(el),
+                depth=torch.stack(depth), semantic=torch.stack(label))
+
+
+def footprint_ids(lay, obs_b, device):
+    """Flat ids of the 8-corner footprint of every valid point, from the HIP
+    integer outputs (the reference's index arithmetic, projection.py:280-298)."""
+    from mass_amd.utils.projection import unproject_bin
+    ix, iy, iz, rx, ry, rz, valid = unproject_bin(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays,
+                                                  lay._poses(obs_b["position"], obs_b["yaw"], obs_b["elevation"]),
+                                                  obs_b["depth"].to(device))
+    v = valid.bool()
+    s = (lay.map_height, lay.map_width, lay.map_depth)
+    axes = []
+    for k, r, size in ((iy[v], ry[v], s[0]), (ix[v], rx[v], s[1]), (iz[v], rz[v], s[2])):
+        lo = torch.where(r < 0.5, (k - 1).clamp(min=0), k)
+        hi = torch.where(r < 0.5, k, (k + 1).clamp(max=size - 1))
+        axes.append((lo, hi))
+    ids = [((a * s[1] + b) * s[2] + c) for a in axes[0] for b in axes[1] for c in axes[2]]
+    return torch.unique(torch.cat(ids))
+
+
+def test_config2_touched_set_and_oracle_256(device):
+    """One distribution-A frame into 256^3 x 54: the set of voxels that change
+    equals the footprint set exactly; values agree with the oracle."""
+    from oracle import massref as orc
+    fr = dist_a_frames(1)
+    lay = semantic_layer(256, device)
+    lay.data.fill_(0.125)            # non-zero background so every touched voxel changes
+    before = lay.data.clone()
+    lay.update_batch(fr)
+    changed = (lay.data != before).any(-1).reshape(-1).nonzero()[:, 0]
+    want = footprint_ids(lay, fr, device)
+    assert torch.equal(changed, want)
+    ol = orc.RefProjectionLayer(camera_height=480, camera_width=640, map_height=256, map_width=256, map_depth=256,
+                                feature_size=54, grid_resolution=0.05)
+    ol.data.fill_(0.125)
+    T = ol.update(dict(position=fr["position"][0], yaw=fr["yaw"][0], elevation=fr["elevation"][0],
+                       depth=fr["depth"][0],
+                       features=torch.nn.functional.one_hot(fr["semantic"][0].long(), 54).float()))
+    assert T == want.numel()
+    assert_map_close(lay.data.cpu().numpy(), ol.data.numpy())
+
+
+def test_config2_batch_equals_repeated_updates_and_is_stable(device):
+    """8 frames: one sequential batch call == 8 update() calls == itself run twice
+    (LDS atomics reorder fp32 sums, so 'equal' means the 1e-4 tolerance);
+    merged mode differs from sequential (SURVEY: max |d| ~ 0.49)."""
+    fr = dist_a_frames(8)
+    a = semantic_layer(256, device)
+    a.update_batch(fr, sequential=True)
+    b = semantic_layer(256, device)
+    for i in range(8):
+        b.update({k: v[i] for k, v in fr.items() if k != "semantic"} | {"semantic": fr["semantic"][i][..., None]})
+    A, B = a.data.cpu().numpy(), b.data.cpu().numpy()
+    assert_map_close(A, B, what="batch vs loop")
+    del b
+    c = semantic_layer(256, device)
+    c.update_batch(fr, sequential=True)
+    assert_map_close(c.data.cpu().numpy(), A, what="run to run")
+    c.reset()
+    c.update_batch(fr, sequential=False)
+    assert np.abs(c.data.cpu().numpy() - A).max() > 0.05
+
+
+def test_config3_three_maps_trajectory_vs_oracle(device):
+    """Config 3 shape at reduced size: a camera circling a box room, per frame
+    occupancy (ones), semantic (labels) and RGB (dense C=3) maps, sequential."""
+    from oracle import massref as orc
+    from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+    from mass_amd.nn.applications.occupancy_projection_layer import OccupancyProjectionLayer
+    from mass_amd.episodes import room_trajectory
+    h, w, m, md, n = 120, 160, 96, 48, 12
+    tr = room_trajectory(n, h, w, seed=3)
+    kw = dict(camera_height=h, camera_width=w, map_height=m, map_width=m, map_depth=md, grid_resolution=0.1)
+    occ = OccupancyProjectionLayer(**kw).to(device)
+    sem = semantic_layer(m, device, h=h, w=w, md=md)
+    sem.grid_resolution = 0.1; sem.reset()
+    rgb = BaseProjectionLayer(feature_size=3, **kw).to(device)
+    o_occ = orc.RefProjectionLayer(feature_size=1, **kw)
+    o_sem = orc.RefProjectionLayer(feature_size=54, **kw)
+    o_rgb = orc.RefProjectionLayer(feature_size=3, **kw)
+    for t in range(n):
+        base = dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t], depth=tr["depth"][t])
+        occ.update(base)
+        sem.update(dict(base, semantic=tr["semantic"][t][..., None]))
+        rgb.update(dict(base, features=tr["rgb"][t]))
+        o_occ.update(dict(base, features=torch.ones_like(tr["depth"][t])))
+        o_sem.update(dict(base, features=torch.nn.functional.one_hot(tr["semantic"][t].long(), 54).float()))
+        o_rgb.update(dict(base, features=tr["rgb"][t]))
+    assert_map_close(occ.data.cpu().numpy(), o_occ.data.numpy(), what="occupancy")
+    assert_map_close(sem.data.cpu().numpy(), o_sem.data.numpy(), what="semantic")
+    assert_map_close(rgb.data.cpu().numpy(), o_rgb.data.numpy(), what="rgb")
+    assert int((o_occ.data != 0).sum()) > 1000

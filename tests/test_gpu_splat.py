@@ -1,0 +1,155 @@
+"""HIP map update against the reference's recorded maps (tests/golden/splat_small.npz,
+edge_cases.npz): occupancy pattern exact, fp32 values within 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SMALL, POSE_OF_FRAME, assert_map_close
+
+pytestmark = pytest.mark.gpu
+H, W, MAP, RES = SMALL["H"], SMALL["W"], SMALL["MAP"], SMALL["RES"]
+CASES = [(1, "ones"), (3, "dense"), (5, "dense"), (5, "label")]
+
+
+def make_layer(C, kind, device, iw=0.5):
+    from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+    from mass_amd.nn.applications.occupancy_projection_layer import OccupancyProjectionLayer
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    kw = dict(camera_height=H, camera_width=W, vertical_fov=90.0, map_height=MAP, map_width=MAP, map_depth=MAP,
+              grid_resolution=RES, interpolation_weight=iw)
+    if kind == "ones":
+        lay = OccupancyProjectionLayer(**kw)
+    elif kind == "label":
+        lay = SemanticProjectionLayer(feature_size=C, **kw)
+    else:
+        lay = BaseProjectionLayer(feature_size=C, **kw)
+    return lay.train().to(device)
+
+
+def obs_of(splat, geom, C, kind, j):
+    tag = f"C{C}{kind}_"
+    pi = POSE_OF_FRAME[j]
+    o = dict(position=geom[f"p{pi}_position"], yaw=float(geom[f"p{pi}_yaw"][0]),
+             elevation=float(geom[f"p{pi}_elevation"][0]), depth=splat[tag + f"f{j}_depth"])
+    if kind == "dense":
+        o["features"] = splat[tag + f"f{j}_feat"]
+    if kind == "label":
+        o["semantic"] = splat[tag + f"f{j}_label"][..., None]
+    return o
+
+
+@pytest.mark.parametrize("C,kind", CASES)
+def test_update_sequential(splat, geom, device, C, kind):
+    lay = make_layer(C, kind, device)
+    for j in range(3):
+        assert lay.update(obs_of(splat, geom, C, kind, j)) is lay
+        assert_map_close(lay.data.cpu().numpy(), splat[f"C{C}{kind}_seq{j}_map"], what=f"frame {j}")
+
+
+def batch_obs(splat, geom, C, kind):
+    obs = [obs_of(splat, geom, C, kind, j) for j in range(3)]
+    out = dict(position=np.stack([o["position"] for o in obs]), yaw=np.array([o["yaw"] for o in obs], np.float32),
+               elevation=np.array([o["elevation"] for o in obs], np.float32),
+               depth=np.stack([o["depth"] for o in obs]))
+    for k in ("features", "semantic"):
+        if k in obs[0]:
+            out[k] = np.stack([o[k] for o in obs])
+    return out
+
+
+@pytest.mark.parametrize("C,kind", CASES)
+def test_update_batch_sequential_equals_three_updates(splat, geom, device, C, kind):
+    lay = make_layer(C, kind, device)
+    lay.update_batch(batch_obs(splat, geom, C, kind), sequential=True)
+    assert_map_close(lay.data.cpu().numpy(), splat[f"C{C}{kind}_seq2_map"])
+
+
+@pytest.mark.parametrize("C,kind", CASES)
+def test_update_batch_merged(splat, geom, device, C, kind):
+    lay = make_layer(C, kind, device)
+    lay.update_batch(batch_obs(splat, geom, C, kind), sequential=False)
+    assert_map_close(lay.data.cpu().numpy(), splat[f"C{C}{kind}_merged_map"])
+
+
+@pytest.mark.parametrize("C,kind", CASES)
+def test_update_onto_nonzero_map(splat, geom, device, C, kind):
+    lay = make_layer(C, kind, device, iw=0.3)
+    lay.data.copy_(torch.tensor(splat[f"C{C}{kind}_init_map"]))
+    lay.update(obs_of(splat, geom, C, kind, 0))
+    assert_map_close(lay.data.cpu().numpy(), splat[f"C{C}{kind}_onto_map"])
+
+
+def test_one_hot_dense_equals_label_path(splat, geom, device):
+    """BaseProjectionLayer.update with an explicit one-hot fp32 image (what the
+    reference's SemanticProjectionLayer builds) == the label path."""
+    C = 5
+    base = make_layer(C, "dense", device)
+    for j in range(3):
+        o = obs_of(splat, geom, C, "label", j)
+        lab = torch.tensor(o.pop("semantic")[..., 0])
+        o["features"] = torch.nn.functional.one_hot(lab, C).float()
+        base.update(o)
+    assert_map_close(base.data.cpu().numpy(), splat["C5label_seq2_map"])
+
+
+def test_functional_api_on_edge_cases(edge, device):
+    """bin_rays + update_feature_map through the functional mirror, on the
+    border / clamped-corner / on-edge points."""
+    from mass_amd.utils.projection import bin_rays, update_feature_map
+    d = lambda k: torch.tensor(edge[k]).to(device)
+    i0, i1, i2, r0, r1, r2, f = bin_rays(d("bins_x"), d("bins_y"), d("bins_z"), d("origin"), d("rays"),
+                                         d("depth"), d("feat"))
+    m = torch.full((MAP, MAP, MAP, 2), float(edge["init_value"]), device=device)
+    update_feature_map(i1, i0, i2, r1, r0, r2, f, m, interpolation_weight=0.5)
+    assert_map_close(m.cpu().numpy(), edge["map_after"])
+
+
+def test_feature_upsampling(splat, geom, device):
+    """features at 1/4 resolution are repeat_interleaved (base_projection_layer.py:322-325)."""
+    C = 3
+    o = obs_of(splat, geom, C, "dense", 0)
+    small = torch.tensor(o["features"])[::4, ::4].contiguous()
+    a = make_layer(C, "dense", device)
+    a.update(dict(o, features=small))
+    b = make_layer(C, "dense", device)
+    full = small.repeat_interleave(4, 0).repeat_interleave(4, 1)
+    b.update(dict(o, features=full))
+    assert_map_close(a.data.cpu().numpy(), b.data.cpu().numpy())
+    # and against the oracle
+    from oracle import massref as orc
+    ol = orc.RefProjectionLayer(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
+                                feature_size=C, grid_resolution=RES)
+    ol.update(dict(o, features=small))
+    assert_map_close(a.data.cpu().numpy(), ol.data.numpy())
+
+
+def test_empty_and_all_invalid_frames(device):
+    lay = make_layer(3, "dense", device)
+    before = lay.data.clone()
+    lay.update(dict(position=[0, 0, 0], yaw=0.0, elevation=0.0, depth=np.full((H, W, 1), 50.0, np.float32),
+                    features=np.ones((H, W, 3), np.float32)))
+    lay.update(dict(position=[0, 0, 0], yaw=0.0, elevation=0.0, depth=np.full((H, W, 1), np.nan, np.float32),
+                    features=np.ones((H, W, 3), np.float32)))
+    assert torch.equal(lay.data, before)
+
+
+def test_reset_and_large_channel_count(device):
+    """C = 300 exercises the small-tile configuration; checked against the oracle."""
+    from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+    from oracle import massref as orc
+    C = 300
+    kw = dict(camera_height=24, camera_width=32, map_height=20, map_width=24, map_depth=12, feature_size=C,
+              grid_resolution=0.1, origin_y=0.3, origin_x=-0.2, origin_z=0.1)
+    lay = BaseProjectionLayer(**kw).to(device)
+    ol = orc.RefProjectionLayer(**kw)
+    g = torch.Generator().manual_seed(9)
+    for t in range(2):
+        o = dict(position=[0.1 * t, -0.1, 0.2], yaw=0.4 + t, elevation=-0.3,
+                 depth=(0.2 + 1.2 * torch.rand(24, 32, 1, generator=g)).numpy(),
+                 features=torch.rand(24, 32, C, generator=g).numpy())
+        lay.update(o); ol.update(o)
+    assert_map_close(lay.data.cpu().numpy(), ol.data.numpy())
+    lay.reset(origin_y=1.0, origin_x=2.0, origin_z=0.5); ol.reset(origin_y=1.0, origin_x=2.0, origin_z=0.5)
+    assert not lay.data.any()
+    for ax in "xyz":
+        assert np.array_equal(getattr(lay, "bins_" + ax).cpu().numpy(), getattr(ol, "bins_" + ax).numpy())

@@ -38,7 +38,8 @@ torch.set_num_threads(8)
 
 
 def np32(t):
-    return np.ascontiguousarray(torch.as_tensor(t, dtype=torch.float32).numpy())
+    # always a copy: layer.data keeps changing after a snapshot is taken
+    return np.array(torch.as_tensor(t, dtype=torch.float32).numpy(), dtype=np.float32, order='C', copy=True)
 
 
 def check_equal(name, a, b):
