@@ -7,6 +7,11 @@ tensors that are not on a HIP device.
 import ctypes
 import os
 
+# torch ships its own libamdhip64.so; it has to be in the process BEFORE
+# libmassfuse.so is loaded so that both bind to the same HIP runtime (two
+# runtimes in one process do not see each other's device pointers).
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmassfuse.so")
 
@@ -69,6 +74,11 @@ def _load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C mass_amd/csrc` (hipcc, --offload-arch=gfx950). mass_amd has no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    with open("/proc/self/maps") as maps:
+        runtimes = {line.split()[-1] for line in maps if "libamdhip64" in line}
+    if len(runtimes) > 1:
+        raise ImportError(f"two HIP runtimes are loaded ({sorted(runtimes)}); import torch before anything "
+                          "that links libamdhip64")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args

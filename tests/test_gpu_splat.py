@@ -29,8 +29,8 @@ def make_layer(C, kind, device, iw=0.5):
 def obs_of(splat, geom, C, kind, j):
     tag = f"C{C}{kind}_"
     pi = POSE_OF_FRAME[j]
-    o = dict(position=geom[f"p{pi}_position"], yaw=float(geom[f"p{pi}_yaw"][0]),
-             elevation=float(geom[f"p{pi}_elevation"][0]), depth=splat[tag + f"f{j}_depth"])
+    o = dict(position=geom[f"p{pi}_position"], yaw=float(geom[f"p{pi}_yaw"].reshape(-1)[0]),
+             elevation=float(geom[f"p{pi}_elevation"].reshape(-1)[0]), depth=splat[tag + f"f{j}_depth"])
     if kind == "dense":
         o["features"] = splat[tag + f"f{j}_feat"]
     if kind == "label":
