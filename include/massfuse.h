@@ -145,6 +145,19 @@ MF_API int mf_update_feature_map(const mf_grid *grid, int64_t n,
                           const void *feat, int32_t feat_kind, float interpolation_weight,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- diagnostics ------------------------------------------------------------ */
+
+/* Stage timing of the fuse pipeline for the roofline report (bench.py): after
+ * mf_profile_enable(1), each of the next (up to 256) mf_fuse_frames /
+ * mf_update_feature_map calls records HIP events on its stream between its
+ * stages, without synchronising.  mf_profile_read(call, ms) waits for profiled
+ * call number `call` (0-based since the enable) and writes milliseconds
+ *   ms[0] zero + count   ms[1] scan   ms[2] scatter   ms[3] fuse_tiles   ms[4] whole call;
+ * it returns the number of calls recorded so far, or <0.
+ * Process-wide, not thread safe; off by default. */
+MF_API int mf_profile_enable(int32_t on);
+MF_API int mf_profile_read(int32_t call, float *ms /* [5] host */);
+
 /* ---- matching (experimentation.py:261-265, 277-280, 284-287) --------------- */
 
 #define MF_METRIC_L2       0  /* || f0_i - f1_j ||_2, difference form (reference arithmetic)          */

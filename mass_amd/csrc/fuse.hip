@@ -26,6 +26,7 @@
 //                features, and finally write the touched voxels back.
 // No global float atomics are used (they run at ~1.3 TB/s and 17x slower when
 // scattered); HBM sees each touched voxel once per call, coalesced along z.
+#include <cstdlib>
 #include "common.h"
 #include "geometry.h"
 
@@ -55,6 +56,7 @@ struct FuseParams {
     // tiling
     int s0, s1, s2;            // log2 tile extents
     int nt0, nt1, nt2, n_tiles, n_keys;
+    int gc;                    // frames per chunk in the tile kernel
     unsigned magicC;           // ceil(2^32 / C) (0 when C == 1)
     // workspace
     int *cursor;               // [n_keys + 1]
@@ -295,24 +297,52 @@ __device__ __forceinline__ void for_corners(const FuseParams &P, const uint4 &r,
     }
 }
 
+constexpr int MAX_CHUNK = 16;          // frames whose W / S2 accumulators are live at once
+constexpr float RESCALE_BELOW = 9.094947e-13f;   // 2^-40: fold the lazy decay into the deltas below this
+
+// One workgroup per map tile, all frames of the call.
+//
+// For a voxel v the reference's sequential blend over frames f = 1..n is the
+// affine recurrence  m_f = a_f * m_{f-1} + g_f * U_f  with
+//   a_f = 1 - iw*S2_f/W_f,  g_f = iw/W_f,  U_f[c] = sum_k w_k^2 feat_k[c]
+// (W_f, S2_f, U_f sums over the frame's corner contributions to v; frames that do
+// not touch v have a_f = 1, U_f = 0).  Unrolled:
+//   m_n = (prod_f a_f) * m_0 + s_n * sum_f (g_f / s_f) * U_f ,   s_f = prod_{f' <= f} a_f'
+// so the C-wide decay of the reference becomes ONE scalar multiply per voxel and
+// frame (s_f), every contribution is a single LDS float atomic scaled by
+// k_f = g_f / s_f, contributions of all frames commute, and the old map value m_0
+// is only needed in the final pass, where each touched voxel is read, combined and
+// written exactly once.  s is kept away from underflow by folding it into the
+// LDS deltas whenever it drops below 2^-40 (a_f can be 0 when iw = 1).
+//
+// LDS: D[TV][C] deltas, W/S2 accumulators for up to `gc` frames at a time,
+// s and prod(a) per voxel.  Frames are processed in chunks of `gc` NON-EMPTY
+// frames: pass 1 accumulates W, S2 (LDS float atomics), pass 2 walks the chunk's
+// frames per voxel to turn them into k_f, pass 3 adds k_f * w^2 * feat.
+//
 // KIND: 0 = ones (C == 1), 1 = labels, 2 = dense fp32 features
-template <int KIND>
-__global__ __launch_bounds__(1024) void fuse_tiles_kernel(FuseParams P)
+template <int KIND, int MAXT>
+__global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x, NT = blockDim.x;
     const int C = P.C;
     const int sv = P.s0 + P.s1 + P.s2;
     const int TV = 1 << sv;
-    float *mapT = smem;                        // [TV][C]
-    float *Wl = mapT + (size_t)TV * C;         // [TV]  W, then iw/W
-    float *Sl = Wl + TV;                       // [TV]  S2, then 1 - iw*S2/W
-    int *offs = (int *)(Sl + TV);              // [MAX_GROUPS + 1]
-    int *misc = offs + MAX_GROUPS + 1;         // [0] ticket, [1] touched count
-    uint32_t *flags = (uint32_t *)(misc + 3);  // [TV]
-    unsigned short *tlist = (unsigned short *)(flags + TV);   // [TV]
+    const int GC = P.gc;
+    float *D = smem;                               // [TV][C] accumulated deltas (in units of s)
+    float *Wl = D + (size_t)TV * C;                // [GC][TV]  W_f, then k_f
+    float *Sl = Wl + (size_t)GC * TV;              // [GC][TV]  S2_f
+    float *sc = Sl + (size_t)GC * TV;              // [TV] s: decay not yet folded into D
+    float *osc = sc + TV;                          // [TV] prod a_f: factor of the old map value
+    int *offs = (int *)(osc + TV);                 // [MAX_GROUPS + 1] bucket starts of this tile
+    int *cb = offs + MAX_GROUPS + 1;               // [MAX_CHUNK + 1] entry offsets of the chunk's frames
+    int *misc = cb + MAX_CHUNK + 1;                // [0] ticket, [1] non-empty frame count
+    unsigned short *ne = (unsigned short *)(misc + 2);   // [MAX_GROUPS] non-empty frames, ascending
+    unsigned char *touched = (unsigned char *)(ne + MAX_GROUPS);   // [TV]
     const int G = P.G;
     const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
+    const unsigned n_el = (unsigned)TV * (unsigned)C;
 
     for (;;) {
         if (tid == 0) misc[0] = atomicAdd(P.ticket, 1);
@@ -322,73 +352,85 @@ __global__ __launch_bounds__(1024) void fuse_tiles_kernel(FuseParams P)
         const int kb = tile * G;
         for (int g = tid; g <= G; g += NT) offs[g] = (kb + g > 0) ? P.cursor[kb + g - 1] : 0;
         __syncthreads();
-        const int e0 = offs[0], e1 = offs[G];
-        if (e0 == e1) { __syncthreads(); continue; }
+        if (offs[0] == offs[G]) { __syncthreads(); continue; }
         const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
         const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
 
-        // ---- which voxels of the tile does this call touch? -----------------
-        for (int v = tid; v < TV; v += NT) flags[v] = 0;
-        __syncthreads();
-        for (int e = e0 + tid; e < e1; e += NT) {
-            const uint4 r = P.rec[e];
-            for_corners(P, r, o0, o1, o2, [&](int v, float) { flags[v] = 1u; });
-        }
-        __syncthreads();
-
-        // ---- load touched voxels (coalesced along z / channel) ---------------
-        const unsigned n_el = (unsigned)TV * (unsigned)C;
-        for (unsigned i = tid; i < n_el; i += NT) {
-            const unsigned v = div_magic(i, P.magicC);
-            if (flags[v]) {
-                const unsigned c = i - v * C;
-                const int l2 = v & m2, l1 = (v >> P.s2) & m1, l0 = v >> (P.s1 + P.s2);
-                const size_t gv = ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2);
-                mapT[i] = P.map[gv * C + c];
+        // compact the non-empty frames in order (wave 0), clear the tile state (everyone)
+        if (tid < 64) {
+            int count = 0;
+            for (int b = 0; b < G; b += 64) {
+                const int g = b + tid;
+                const bool f = g < G && offs[g + 1] > offs[g];
+                const unsigned long long m = __ballot(f);
+                if (f) ne[count + __popcll(m & ((1ull << tid) - 1ull))] = (unsigned short)g;
+                count += __popcll(m);
             }
+            if (tid == 0) misc[1] = count;
         }
+        for (unsigned i = tid; i < n_el; i += NT) D[i] = 0.0f;
+        for (int v = tid; v < TV; v += NT) { sc[v] = 1.0f; osc[v] = 1.0f; touched[v] = 0; }
         __syncthreads();
+        const int n_ne = misc[1];
 
-        // ---- groups (frames) in order -----------------------------------------
-        for (int g = 0; g < G; ++g) {
-            const int ga = offs[g], gb = offs[g + 1];
-            if (ga == gb) continue;
-            for (int v = tid; v < TV; v += NT) { Wl[v] = 0.0f; Sl[v] = 0.0f; }
-            if (tid == 0) misc[1] = 0;
+        for (int c0 = 0; c0 < n_ne; c0 += GC) {
+            const int nc = min(GC, n_ne - c0);
+            for (int i = tid; i < nc * TV; i += NT) {
+                const int j = i >> sv, v = i & (TV - 1);
+                Wl[j * TV + v] = 0.0f; Sl[j * TV + v] = 0.0f;
+            }
+            if (tid <= nc) cb[tid] = tid < nc ? offs[ne[c0 + tid]] : offs[ne[c0 + nc - 1] + 1];
             __syncthreads();
-            for (int e = ga + tid; e < gb; e += NT) {
+            const int ea = cb[0], eb = cb[nc];
+            // slot of entry e inside the chunk = number of frame starts cb[1..nc-1] that are <= e
+            auto slot_of = [&](int e) { int j = 0; for (int q = 1; q < nc; ++q) j += e >= cb[q]; return j; };
+
+            // pass 1: W_f, S2_f
+            for (int e = ea + tid; e < eb; e += NT) {
                 const uint4 r = P.rec[e];
-                for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&Wl[v], w); atomicAdd(&Sl[v], w * w); });
+                const int base = slot_of(e) * TV;
+                for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                    atomicAdd(&Wl[base + v], w); atomicAdd(&Sl[base + v], w * w);
+                });
             }
             __syncthreads();
+            // pass 2: per voxel, frames in order: s *= a_f, k_f = g_f / s
             for (int v = tid; v < TV; v += NT) {
-                const float Wv = Wl[v];
-                if (Wv > 0.0f) {
-                    Sl[v] = 1.0f - P.iw * (Sl[v] / Wv);
-                    Wl[v] = P.iw / Wv;
-                    tlist[atomicAdd(&misc[1], 1)] = (unsigned short)v;
+                float s = sc[v], o = osc[v];
+                bool any = false;
+                for (int j = 0; j < nc; ++j) {
+                    const float Wv = Wl[j * TV + v];
+                    if (Wv > 0.0f) {
+                        const float rW = __builtin_amdgcn_rcpf(Wv);
+                        const float a = 1.0f - P.iw * (Sl[j * TV + v] * rW);
+                        o *= a; s *= a;
+                        if (!(s >= RESCALE_BELOW)) {
+                            for (int c = 0; c < C; ++c) D[v * C + c] *= s;
+                            s = 1.0f;
+                        }
+                        Wl[j * TV + v] = P.iw * rW * __builtin_amdgcn_rcpf(s);
+                        any = true;
+                    }
                 }
+                if (any) { sc[v] = s; osc[v] = o; touched[v] = 1; }
             }
             __syncthreads();
-            const unsigned n_dec = (unsigned)misc[1] * (unsigned)C;
-            for (unsigned i = tid; i < n_dec; i += NT) {
-                const unsigned q = div_magic(i, P.magicC);
-                const unsigned v = tlist[q];
-                const unsigned j = v * C + (i - q * C);
-                mapT[j] *= Sl[v];
-            }
-            __syncthreads();
+            // pass 3: D += k_f * w^2 * feat
             if (KIND == 0) {
-                for (int e = ga + tid; e < gb; e += NT) {
+                for (int e = ea + tid; e < eb; e += NT) {
                     const uint4 r = P.rec[e];
-                    for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&mapT[v], (w * w) * Wl[v]); });
+                    const int base = slot_of(e) * TV;
+                    for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&D[v], (w * w) * Wl[base + v]); });
                 }
             } else if (KIND == 1) {
-                for (int e = ga + tid; e < gb; e += NT) {
+                for (int e = ea + tid; e < eb; e += NT) {
                     const uint4 r = P.rec[e];
                     const uint32_t label = P.aux[e];
+                    const int base = slot_of(e) * TV;
                     if (label < (uint32_t)C)
-                        for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&mapT[v * C + label], (w * w) * Wl[v]); });
+                        for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                            atomicAdd(&D[v * C + label], (w * w) * Wl[base + v]);
+                        });
                 }
             } else {
                 // lanes-per-entry: the smallest power of two >= min(C, 64)
@@ -396,26 +438,27 @@ __global__ __launch_bounds__(1024) void fuse_tiles_kernel(FuseParams P)
                 while (lpe < C && lpe < 64) lpe <<= 1;
                 const int sub = tid & (lpe - 1);
                 const int per = NT / lpe;
-                for (int e = ga + tid / lpe; e < gb; e += per) {
+                for (int e = ea + tid / lpe; e < eb; e += per) {
                     const uint4 r = P.rec[e];
                     const float *f = (const float *)P.feat + (size_t)P.aux[e] * C;
+                    const int base = slot_of(e) * TV;
                     for_corners(P, r, o0, o1, o2, [&](int v, float w) {
-                        const float s = (w * w) * Wl[v];
-                        for (int c = sub; c < C; c += lpe) atomicAdd(&mapT[v * C + c], s * f[c]);
+                        const float q = (w * w) * Wl[base + v];
+                        for (int c = sub; c < C; c += lpe) atomicAdd(&D[v * C + c], q * f[c]);
                     });
                 }
             }
             __syncthreads();
         }
 
-        // ---- write back ---------------------------------------------------------
+        // final pass: every touched voxel is read, combined and written once
         for (unsigned i = tid; i < n_el; i += NT) {
             const unsigned v = div_magic(i, P.magicC);
-            if (flags[v]) {
+            if (touched[v]) {
                 const unsigned c = i - v * C;
                 const int l2 = v & m2, l1 = (v >> P.s2) & m1, l0 = v >> (P.s1 + P.s2);
-                const size_t gv = ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2);
-                P.map[gv * C + c] = mapT[i];
+                const size_t gi = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2)) * C + c;
+                P.map[gi] = osc[v] * P.map[gi] + sc[v] * D[i];
             }
         }
         __syncthreads();
@@ -489,10 +532,26 @@ static int ilog2_floor(unsigned x) { int l = 0; while ((2u << l) <= x) ++l; retu
 // Tile extents: the largest power-of-two voxel count whose LDS image
 // (C floats of map + W + S2 + flag + list per voxel) fits ~140 KB, capped at
 // 1024 voxels; z gets up to 8 (16 for >= 1024 voxels) so that HBM runs stay long.
+// Tuning override for experiments: MF_TILE="s0 s1 s2 threads" (log2 extents).
+static bool tile_override(int &s0, int &s1, int &s2, int &nt)
+{
+    static int v[4] = {-1, -1, -1, -1};
+    static bool parsed = false, have = false;
+    if (!parsed) {
+        parsed = true;
+        const char *e = getenv("MF_TILE");
+        have = e && sscanf(e, "%d %d %d %d", &v[0], &v[1], &v[2], &v[3]) == 4;
+    }
+    if (have) { s0 = v[0]; s1 = v[1]; s2 = v[2]; nt = v[3]; }
+    return have;
+}
+
 static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
 {
-    const size_t budget = 140 * 1024 - 4 * (MAX_GROUPS + 8);
-    size_t per_voxel = (size_t)g->channels * 4 + 4 + 4 + 4 + 2;
+    int nt_unused;
+    if (tile_override(s0, s1, s2, nt_unused)) return;
+    const size_t budget = 156 * 1024 - 32 * 1024 - 4 * (MAX_GROUPS + 32) - 2 * MAX_GROUPS;
+    size_t per_voxel = (size_t)g->channels * 4 + 8 + 1;
     unsigned tv = (unsigned)(budget / per_voxel);
     if (tv < 1) tv = 1;
     if (tv > 1024) tv = 1024;
@@ -504,10 +563,20 @@ static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
     s0 = rem - s1;
 }
 
-static size_t tile_lds_bytes(int C, int sv)
+static int chunk_frames(int sv, int G)
+{
+    int gc = (32 * 1024) / ((1 << sv) * 8);      // W + S2 accumulators stay within 32 KB
+    if (gc > MAX_CHUNK) gc = MAX_CHUNK;
+    if (gc > G) gc = G;
+    if (gc < 1) gc = 1;
+    return gc;
+}
+
+static size_t tile_lds_bytes(int C, int sv, int gc)
 {
     const size_t TV = (size_t)1 << sv;
-    return TV * C * 4 + TV * 4 * 2 + (MAX_GROUPS + 1 + 3) * 4 + TV * 4 + TV * 2 + 16;
+    return TV * C * 4 + (size_t)gc * TV * 8 + TV * 8 + (MAX_GROUPS + 1) * 4 + (MAX_CHUNK + 1) * 4 + 2 * 4 +
+           MAX_GROUPS * 2 + TV + 16;
 }
 
 struct Layout {
@@ -595,6 +664,19 @@ static void fill_frames(FuseParams &P, const mf_frames *f)
     P.n_points = (long long)f->n_frames * f->height * f->width;
 }
 
+// Optional per-stage timing (bench.py's roofline leg): HIP events recorded on
+// the caller's stream between the pipeline stages of the most recent call.
+constexpr int PROF_CALLS = 256;
+static bool g_profile = false;
+static hipEvent_t g_ev[PROF_CALLS][5];
+static bool g_ev_ready = false;
+static int g_prof_calls = 0;       // profiled calls since mf_profile_enable(1)
+
+static void prof_mark(int i, hipStream_t st)
+{
+    if (g_profile && g_ev_ready && g_prof_calls < PROF_CALLS) (void)hipEventRecord(g_ev[g_prof_calls][i], st);
+}
+
 template <int FRONT>
 static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, size_t workspace_bytes, hipStream_t st)
 {
@@ -618,37 +700,49 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     P.n_tiles = P.nt0 * P.nt1 * P.nt2;
     P.n_keys = L.n_keys;
 
+    prof_mark(0, st);
     // cursor .. ticket are contiguous: one memset
     MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, L.rec - L.cursor, st));
     const unsigned bin_blocks = (unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS);
     hipLaunchKernelGGL(count_kernel<FRONT>, dim3(bin_blocks), dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
+    prof_mark(1, st);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
                        (const int *)P.cursor, P.n_keys + 1, P.block_sums);
     MF_LAUNCH_CHECK("scan_sums_kernel");
     hipLaunchKernelGGL(scan_apply_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
                        P.cursor, P.n_keys + 1, (const int *)P.block_sums);
     MF_LAUNCH_CHECK("scan_apply_kernel");
+    prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, dim3(bin_blocks), dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
+    prof_mark(3, st);
 
     const int sv = P.s0 + P.s1 + P.s2;
-    const size_t lds = tile_lds_bytes(P.C, sv);
+    P.gc = chunk_frames(sv, P.G);
+    const size_t lds = tile_lds_bytes(P.C, sv, P.gc);
     const DeviceInfo &dev = device_info();
     if (lds > (size_t)dev.lds_per_cu)
         return fail(MF_ERR_INVALID, "tile needs %zu bytes of LDS, device has %d", lds, dev.lds_per_cu);
-    const int nt = ((size_t)(1 << sv) * P.C >= 8192) ? 1024 : 256;
+    int nt = ((size_t)(1 << sv) * P.C >= 8192) ? 1024 : 256;
+    { int a, b, c; tile_override(a, b, c, nt); }
     int per_cu = (int)((size_t)dev.lds_per_cu / lds);
+    if (per_cu > 16) per_cu = 16;
     const int by_threads = 2048 / nt;
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
     int blocks = dev.cus * per_cu;
     if (blocks > P.n_tiles) blocks = P.n_tiles;
     const int kind = P.feat_kind == MF_FEAT_ONES ? 0 : (P.feat_kind == MF_FEAT_DENSE_F32 ? 2 : 1);
-    void (*kern)(FuseParams) = kind == 0 ? fuse_tiles_kernel<0> : kind == 1 ? fuse_tiles_kernel<1> : fuse_tiles_kernel<2>;
+    void (*kern)(FuseParams);
+    if (nt <= 64) kern = kind == 0 ? fuse_tiles_kernel<0, 64> : kind == 1 ? fuse_tiles_kernel<1, 64> : fuse_tiles_kernel<2, 64>;
+    else if (nt <= 256) kern = kind == 0 ? fuse_tiles_kernel<0, 256> : kind == 1 ? fuse_tiles_kernel<1, 256> : fuse_tiles_kernel<2, 256>;
+    else kern = kind == 0 ? fuse_tiles_kernel<0, 1024> : kind == 1 ? fuse_tiles_kernel<1, 1024> : fuse_tiles_kernel<2, 1024>;
     MF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, P);
     MF_LAUNCH_CHECK("fuse_tiles_kernel");
+    prof_mark(4, st);
+    if (g_profile && g_ev_ready && g_prof_calls < PROF_CALLS) ++g_prof_calls;
     return MF_OK;
 }
 
@@ -657,6 +751,30 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
 using namespace mf;
 
 extern "C" {
+
+int mf_profile_enable(int32_t on)
+{
+    if (on && !g_ev_ready) {
+        for (int c = 0; c < PROF_CALLS; ++c)
+            for (int i = 0; i < 5; ++i) MF_HIP_CHECK(hipEventCreate(&g_ev[c][i]));
+        g_ev_ready = true;
+    }
+    g_profile = on != 0;
+    if (on) g_prof_calls = 0;
+    return MF_OK;
+}
+
+int mf_profile_read(int32_t call, float *ms)
+{
+    if (!ms) return fail(MF_ERR_INVALID, "ms is NULL");
+    if (call < 0 || call >= g_prof_calls)
+        return fail(MF_ERR_INVALID, "call %d not recorded (%d profiled calls since mf_profile_enable(1))", call,
+                    g_prof_calls);
+    MF_HIP_CHECK(hipEventSynchronize(g_ev[call][4]));
+    for (int i = 0; i < 4; ++i) MF_HIP_CHECK(hipEventElapsedTime(&ms[i], g_ev[call][i], g_ev[call][i + 1]));
+    MF_HIP_CHECK(hipEventElapsedTime(&ms[4], g_ev[call][0], g_ev[call][4]));
+    return g_prof_calls;
+}
 
 size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int32_t n_groups)
 {

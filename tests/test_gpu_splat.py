@@ -153,3 +153,36 @@ def test_reset_and_large_channel_count(device):
     assert not lay.data.any()
     for ax in "xyz":
         assert np.array_equal(getattr(lay, "bins_" + ax).cpu().numpy(), getattr(ol, "bins_" + ax).numpy())
+
+
+@pytest.mark.parametrize("iw,kind,C", [(0.5, "label", 5), (1.0, "dense", 3), (1.0, "ones", 1)])
+def test_long_sequential_batch_vs_oracle_loop(device, iw, kind, C):
+    """40 frames in ONE sequential call: more frames than the tile kernel keeps
+    accumulators for at once (chunking), and with iw = 1 the per-voxel decay
+    product underflows past 2^-40 (lazy-scale folding).  Oracle: 40 update() calls."""
+    from oracle import massref as orc
+    n = 40
+    lay = make_layer(C, kind, device, iw=iw)
+    ol = orc.RefProjectionLayer(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
+                                feature_size=C, grid_resolution=RES, interpolation_weight=iw)
+    g = torch.Generator().manual_seed(11)
+    init = torch.rand(MAP, MAP, MAP, C, generator=g)
+    lay.data.copy_(init); ol.data.copy_(init)
+    pos = 0.05 * torch.randn(n, 3, generator=g)
+    yaw = 0.7 + 0.02 * torch.randn(n, generator=g)
+    el = -0.5 + 0.02 * torch.randn(n, generator=g)
+    depth = 0.6 + 0.9 * torch.rand(n, H, W, 1, generator=g)
+    batch = dict(position=pos, yaw=yaw, elevation=el, depth=depth)
+    if kind == "label":
+        lab = torch.randint(0, C, (n, H, W), generator=g)
+        batch["semantic"] = lab
+        feats = torch.nn.functional.one_hot(lab, C).float()
+    elif kind == "dense":
+        feats = torch.rand(n, H, W, C, generator=g)
+        batch["features"] = feats
+    else:
+        feats = torch.ones(n, H, W, 1)
+    lay.update_batch(batch, sequential=True)
+    for t in range(n):
+        ol.update(dict(position=pos[t], yaw=yaw[t], elevation=el[t], depth=depth[t], features=feats[t]))
+    assert_map_close(lay.data.cpu().numpy(), ol.data.numpy())
