@@ -57,6 +57,7 @@ struct FuseParams {
     int s0, s1, s2;            // log2 tile extents
     int nt0, nt1, nt2, n_tiles, n_keys;
     int gc;                    // frames per chunk in the tile kernel
+    int vec4;                  // final pass may use 16-byte accesses
     unsigned magicC;           // ceil(2^32 / C) (0 when C == 1)
     // workspace
     int *cursor;               // [n_keys + 1]
@@ -297,6 +298,16 @@ __device__ __forceinline__ void for_corners(const FuseParams &P, const uint4 &r,
     }
 }
 
+// Dev-only phase accounting (MF_STAMPS=1): cycles of workgroup-thread 0 between
+// the barriers of the tile kernel, summed over all workgroups.
+__device__ unsigned long long g_stamps[8];
+#define MF_STAMP(i)                                                                   \
+    if (STAMPS && tid == 0) {                                                         \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();                   \
+        atomicAdd(&g_stamps[i], _t - t_last);                                         \
+        t_last = _t;                                                                  \
+    }
+
 constexpr int MAX_CHUNK = 16;          // frames whose W / S2 accumulators are live at once
 constexpr float RESCALE_BELOW = 9.094947e-13f;   // 2^-40: fold the lazy decay into the deltas below this
 
@@ -321,10 +332,11 @@ constexpr float RESCALE_BELOW = 9.094947e-13f;   // 2^-40: fold the lazy decay i
 // frames per voxel to turn them into k_f, pass 3 adds k_f * w^2 * feat.
 //
 // KIND: 0 = ones (C == 1), 1 = labels, 2 = dense fp32 features
-template <int KIND, int MAXT>
+template <int KIND, int MAXT, bool STAMPS = false>
 __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
 {
     extern __shared__ float smem[];
+    unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int C = P.C;
     const int sv = P.s0 + P.s1 + P.s2;
@@ -352,7 +364,8 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
         const int kb = tile * G;
         for (int g = tid; g <= G; g += NT) offs[g] = (kb + g > 0) ? P.cursor[kb + g - 1] : 0;
         __syncthreads();
-        if (offs[0] == offs[G]) { __syncthreads(); continue; }
+        if (offs[0] == offs[G]) { __syncthreads(); MF_STAMP(0) continue; }
+        MF_STAMP(0)
         const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
         const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
 
@@ -371,6 +384,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
         for (unsigned i = tid; i < n_el; i += NT) D[i] = 0.0f;
         for (int v = tid; v < TV; v += NT) { sc[v] = 1.0f; osc[v] = 1.0f; touched[v] = 0; }
         __syncthreads();
+        MF_STAMP(1)
         const int n_ne = misc[1];
 
         for (int c0 = 0; c0 < n_ne; c0 += GC) {
@@ -381,6 +395,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
             }
             if (tid <= nc) cb[tid] = tid < nc ? offs[ne[c0 + tid]] : offs[ne[c0 + nc - 1] + 1];
             __syncthreads();
+            MF_STAMP(2)
             const int ea = cb[0], eb = cb[nc];
             // slot of entry e inside the chunk = number of frame starts cb[1..nc-1] that are <= e
             auto slot_of = [&](int e) { int j = 0; for (int q = 1; q < nc; ++q) j += e >= cb[q]; return j; };
@@ -394,6 +409,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
                 });
             }
             __syncthreads();
+            MF_STAMP(3)
             // pass 2: per voxel, frames in order: s *= a_f, k_f = g_f / s
             for (int v = tid; v < TV; v += NT) {
                 float s = sc[v], o = osc[v];
@@ -415,6 +431,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
                 if (any) { sc[v] = s; osc[v] = o; touched[v] = 1; }
             }
             __syncthreads();
+            MF_STAMP(4)
             // pass 3: D += k_f * w^2 * feat
             if (KIND == 0) {
                 for (int e = ea + tid; e < eb; e += NT) {
@@ -449,19 +466,86 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
                 }
             }
             __syncthreads();
+            MF_STAMP(5)
         }
 
-        // final pass: every touched voxel is read, combined and written once
-        for (unsigned i = tid; i < n_el; i += NT) {
-            const unsigned v = div_magic(i, P.magicC);
-            if (touched[v]) {
-                const unsigned c = i - v * C;
-                const int l2 = v & m2, l1 = (v >> P.s2) & m1, l0 = v >> (P.s1 + P.s2);
-                const size_t gi = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2)) * C + c;
-                P.map[gi] = osc[v] * P.map[gi] + sc[v] * D[i];
+        // final pass: every touched voxel is read, combined and written once, with all of a
+        // thread's loads in flight before the first store (one workgroup per CU: the loop is
+        // otherwise bound by HBM latency).  Rows of the tile (T2 voxels along z = T2*C floats)
+        // are contiguous in the map; when they are 16-byte aligned the pass moves float4s, and a
+        // float4 that straddles a touched and an untouched voxel rewrites the latter unchanged
+        // (s = prod a = 1, D = 0), which is safe because the whole box belongs to this tile.
+        if (P.vec4) {
+            const unsigned row_len = (unsigned)C << P.s2;          // floats per tile row
+            const unsigned n4 = n_el >> 2;
+            const float4 *map4 = reinterpret_cast<const float4 *>(P.map);
+            float4 *map4w = reinterpret_cast<float4 *>(P.map);
+            constexpr int U = 7;
+            for (unsigned b = 0; b < n4; b += NT * U) {
+                float4 old[U];
+                unsigned gq[U], li[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const unsigned q = b + j * NT + tid;
+                    li[j] = 0xffffffffu;
+                    if (q < n4) {
+                        const unsigned i = q << 2;
+                        const unsigned va = div_magic(i, P.magicC), vb = div_magic(i + 3, P.magicC);
+                        bool t = touched[va] | touched[vb];
+                        if (C < 3) t = t | touched[div_magic(i + 1, P.magicC)] | touched[div_magic(i + 2, P.magicC)];
+                        if (t) {
+                            const unsigned r = va >> P.s2;                 // row = (l0, l1)
+                            const int l1 = r & m1, l0 = r >> P.s1;
+                            const size_t g = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len);
+                            gq[j] = (unsigned)(g >> 2);
+                            li[j] = i;
+                            old[j] = map4[gq[j]];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j)
+                    if (li[j] != 0xffffffffu) {
+                        const unsigned i = li[j];
+                        const float4 d = *reinterpret_cast<const float4 *>(D + i);
+                        const unsigned v0 = div_magic(i, P.magicC), v1 = div_magic(i + 1, P.magicC),
+                                       v2 = div_magic(i + 2, P.magicC), v3 = div_magic(i + 3, P.magicC);
+                        float4 o;
+                        o.x = osc[v0] * old[j].x + sc[v0] * d.x;
+                        o.y = osc[v1] * old[j].y + sc[v1] * d.y;
+                        o.z = osc[v2] * old[j].z + sc[v2] * d.z;
+                        o.w = osc[v3] * old[j].w + sc[v3] * d.w;
+                        map4w[gq[j]] = o;
+                    }
+            }
+        } else {
+            constexpr int U = 4;
+            for (unsigned b = 0; b < n_el; b += NT * U) {
+                float old[U];
+                size_t gi[U];
+                unsigned li[U], vv[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const unsigned i = b + j * NT + tid;
+                    li[j] = 0xffffffffu;
+                    if (i < n_el) {
+                        const unsigned v = div_magic(i, P.magicC);
+                        if (touched[v]) {
+                            const unsigned c = i - v * C;
+                            const int l2 = v & m2, l1 = (v >> P.s2) & m1, l0 = v >> (P.s1 + P.s2);
+                            gi[j] = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2)) * C + c;
+                            li[j] = i; vv[j] = v;
+                            old[j] = P.map[gi[j]];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j)
+                    if (li[j] != 0xffffffffu) P.map[gi[j]] = osc[vv[j]] * old[j] + sc[vv[j]] * D[li[j]];
             }
         }
         __syncthreads();
+        MF_STAMP(6)
     }
 }
 
@@ -533,14 +617,16 @@ static int ilog2_floor(unsigned x) { int l = 0; while ((2u << l) <= x) ++l; retu
 // (C floats of map + W + S2 + flag + list per voxel) fits ~140 KB, capped at
 // 1024 voxels; z gets up to 8 (16 for >= 1024 voxels) so that HBM runs stay long.
 // Tuning override for experiments: MF_TILE="s0 s1 s2 threads" (log2 extents).
+static int g_gc_override = -1;
 static bool tile_override(int &s0, int &s1, int &s2, int &nt)
 {
-    static int v[4] = {-1, -1, -1, -1};
+    static int v[5] = {-1, -1, -1, -1, -1};
     static bool parsed = false, have = false;
     if (!parsed) {
         parsed = true;
         const char *e = getenv("MF_TILE");
-        have = e && sscanf(e, "%d %d %d %d", &v[0], &v[1], &v[2], &v[3]) == 4;
+        have = e && sscanf(e, "%d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4]) >= 4;
+        g_gc_override = have ? v[4] : -1;
     }
     if (have) { s0 = v[0]; s1 = v[1]; s2 = v[2]; nt = v[3]; }
     return have;
@@ -566,6 +652,7 @@ static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
 static int chunk_frames(int sv, int G)
 {
     int gc = (32 * 1024) / ((1 << sv) * 8);      // W + S2 accumulators stay within 32 KB
+    if (g_gc_override > 0) gc = g_gc_override;
     if (gc > MAX_CHUNK) gc = MAX_CHUNK;
     if (gc > G) gc = G;
     if (gc < 1) gc = 1;
@@ -720,6 +807,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
 
     const int sv = P.s0 + P.s1 + P.s2;
     P.gc = chunk_frames(sv, P.G);
+    P.vec4 = ((uintptr_t)P.map % 16 == 0) && ((P.C << P.s2) % 4 == 0) && (P.size2 % (1 << P.s2) == 0) &&
+             ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34)) && getenv("MF_NO_VEC4") == nullptr;
     const size_t lds = tile_lds_bytes(P.C, sv, P.gc);
     const DeviceInfo &dev = device_info();
     if (lds > (size_t)dev.lds_per_cu)
@@ -738,11 +827,24 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (nt <= 64) kern = kind == 0 ? fuse_tiles_kernel<0, 64> : kind == 1 ? fuse_tiles_kernel<1, 64> : fuse_tiles_kernel<2, 64>;
     else if (nt <= 256) kern = kind == 0 ? fuse_tiles_kernel<0, 256> : kind == 1 ? fuse_tiles_kernel<1, 256> : fuse_tiles_kernel<2, 256>;
     else kern = kind == 0 ? fuse_tiles_kernel<0, 1024> : kind == 1 ? fuse_tiles_kernel<1, 1024> : fuse_tiles_kernel<2, 1024>;
+    static const bool stamps = getenv("MF_STAMPS") != nullptr;
+    if (stamps && kind == 1 && nt > 256) kern = fuse_tiles_kernel<1, 1024, true>;
+    if (stamps && kind == 1 && nt <= 256 && nt > 64) kern = fuse_tiles_kernel<1, 256, true>;
+    if (stamps) { unsigned long long z[8] = {}; MF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z))); }
     MF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, P);
     MF_LAUNCH_CHECK("fuse_tiles_kernel");
     prof_mark(4, st);
     if (g_profile && g_ev_ready && g_prof_calls < PROF_CALLS) ++g_prof_calls;
+    if (stamps) {
+        unsigned long long z[8];
+        MF_HIP_CHECK(hipStreamSynchronize(st));
+        MF_HIP_CHECK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_stamps), sizeof(z)));
+        double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)z[i];
+        fprintf(stderr, "[MF_STAMPS] blocks=%d nt=%d lds=%zu gc=%d | ticket+offs %.1f%% setup %.1f%% chunk-zero %.1f%% P1 %.1f%% P2 %.1f%% P3 %.1f%% final %.1f%% | total %.3g ticks/block\n",
+                blocks, nt, lds, P.gc, 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot,
+                100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot, tot / blocks);
+    }
     return MF_OK;
 }
 
