@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmassfuse.so")
+LIB_PATH = os.environ.get("MASSFUSE_LIB") or os.path.join(_HERE, "libmassfuse.so")   # override: kernel experiments only
 
 MF_OK, MF_ERR_INVALID, MF_ERR_WORKSPACE, MF_ERR_HIP = 0, -1, -2, -3
 FEAT_ONES, FEAT_LABEL_U8, FEAT_LABEL_I32, FEAT_LABEL_I64, FEAT_DENSE_F32 = 0, 1, 2, 3, 4

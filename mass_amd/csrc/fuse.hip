@@ -67,6 +67,23 @@ struct FuseParams {
     uint32_t *aux;
 };
 
+// What the tile kernel needs (a subset: fewer scalar registers held across its loop).
+struct TileParams {
+    int size0, size1, size2, C;
+    float *map;
+    const void *feat;
+    int G;
+    float iw;
+    int s0, s1, s2;
+    int nt1, nt2, n_tiles;
+    unsigned magicC;
+    int gc, vec4;
+    const int *cursor;
+    int *ticket;
+    const uint4 *rec;
+    const uint32_t *aux;
+};
+
 struct Point {
     int k0, k1, k2;            // map dims: 0 = y (flipped), 1 = x, 2 = z
     float r0, r1, r2;
@@ -279,21 +296,23 @@ __device__ __forceinline__ unsigned div_magic(unsigned n, unsigned magic)   // n
 // Visit the corners of point record r that fall inside the tile whose origin
 // is (o0, o1, o2): body(v, w) gets the tile-local voxel id and the corner weight.
 template <class F>
-__device__ __forceinline__ void for_corners(const FuseParams &P, const uint4 &r, int o0, int o1, int o2, F body)
+__device__ __forceinline__ void for_corners(const TileParams &P, const uint4 &r, int o0, int o1, int o2, F body)
 {
     const int k0 = r.x & 1023, k1 = (r.x >> 10) & 1023, k2 = (r.x >> 20) & 1023;
     const AxisFoot a0 = axis_foot(k0, __uint_as_float(r.y), P.size0);
     const AxisFoot a1 = axis_foot(k1, __uint_as_float(r.z), P.size1);
     const AxisFoot a2 = axis_foot(k2, __uint_as_float(r.w), P.size2);
-    const int i0[2] = {a0.lo - o0, a0.hi - o0}, i1[2] = {a1.lo - o1, a1.hi - o1}, i2[2] = {a2.lo - o2, a2.hi - o2};
-    const float w0[2] = {a0.wlo, a0.whi}, w1[2] = {a1.wlo, a1.whi}, w2[2] = {a2.wlo, a2.whi};
-#pragma unroll
+    // tile-local coordinates of the lower corner and whether the upper one is a different voxel
+    const unsigned l0 = (unsigned)(a0.lo - o0), l1 = (unsigned)(a1.lo - o1), l2 = (unsigned)(a2.lo - o2);
+    const unsigned d0 = (unsigned)(a0.hi - a0.lo), d1 = (unsigned)(a1.hi - a1.lo), d2 = (unsigned)(a2.hi - a2.lo);
+    // rolled on purpose: the body is expanded once, which keeps the kernel inside 128 VGPRs
+#pragma nounroll
     for (int cc = 0; cc < 8; ++cc) {
-        const int ca = cc >> 2, cb = (cc >> 1) & 1, cd = cc & 1;
-        const unsigned l0 = (unsigned)i0[ca], l1 = (unsigned)i1[cb], l2 = (unsigned)i2[cd];
-        if ((l0 >> P.s0) == 0 && (l1 >> P.s1) == 0 && (l2 >> P.s2) == 0) {
-            const int v = (int)((((l0 << P.s1) | l1) << P.s2) | l2);
-            body(v, corner_weight(w0[ca], w1[cb], w2[cd]));
+        const bool ha = cc & 4, hb = cc & 2, hd = cc & 1;
+        const unsigned c0 = l0 + (ha ? d0 : 0u), c1 = l1 + (hb ? d1 : 0u), c2 = l2 + (hd ? d2 : 0u);
+        if ((c0 >> P.s0) == 0 && (c1 >> P.s1) == 0 && (c2 >> P.s2) == 0) {
+            const int v = (int)((((c0 << P.s1) | c1) << P.s2) | c2);
+            body(v, corner_weight(ha ? a0.whi : a0.wlo, hb ? a1.whi : a1.wlo, hd ? a2.whi : a2.wlo));
         }
     }
 }
@@ -308,6 +327,13 @@ __device__ unsigned long long g_stamps[8];
         t_last = _t;                                                                  \
     }
 
+#ifndef MF_EB
+#define MF_EB 2
+#endif
+#ifndef MF_FU
+#define MF_FU 4
+#endif
+constexpr int EB = MF_EB;                  // entries a thread keeps in flight / in registers per batch
 constexpr int MAX_CHUNK = 16;          // frames whose W / S2 accumulators are live at once
 constexpr float RESCALE_BELOW = 9.094947e-13f;   // 2^-40: fold the lazy decay into the deltas below this
 
@@ -333,7 +359,7 @@ constexpr float RESCALE_BELOW = 9.094947e-13f;   // 2^-40: fold the lazy decay i
 //
 // KIND: 0 = ones (C == 1), 1 = labels, 2 = dense fp32 features
 template <int KIND, int MAXT, bool STAMPS = false>
-__global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
+__global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 {
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -400,13 +426,24 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
             // slot of entry e inside the chunk = number of frame starts cb[1..nc-1] that are <= e
             auto slot_of = [&](int e) { int j = 0; for (int q = 1; q < nc; ++q) j += e >= cb[q]; return j; };
 
-            // pass 1: W_f, S2_f
-            for (int e = ea + tid; e < eb; e += NT) {
-                const uint4 r = P.rec[e];
-                const int base = slot_of(e) * TV;
-                for_corners(P, r, o0, o1, o2, [&](int v, float w) {
-                    atomicAdd(&Wl[base + v], w); atomicAdd(&Sl[base + v], w * w);
-                });
+            // pass 1: W_f, S2_f.  Entries are taken EB at a time per thread, all EB loads issued
+            // before the first use (memory-level parallelism: one workgroup per CU).
+            for (int bb = ea; bb < eb; bb += NT * EB) {
+                uint4 r[EB];
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int e = bb + tid + j * NT;
+                    r[j].x = 0xffffffffu;
+                    if (e < eb) r[j] = P.rec[e];
+                }
+#pragma unroll
+                for (int j = 0; j < EB; ++j)
+                    if (r[j].x != 0xffffffffu) {
+                        const int base = slot_of(bb + tid + j * NT) * TV;
+                        for_corners(P, r[j], o0, o1, o2, [&](int v, float w) {
+                            atomicAdd(&Wl[base + v], w); atomicAdd(&Sl[base + v], w * w);
+                        });
+                    }
             }
             __syncthreads();
             MF_STAMP(3)
@@ -433,21 +470,29 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
             __syncthreads();
             MF_STAMP(4)
             // pass 3: D += k_f * w^2 * feat
-            if (KIND == 0) {
-                for (int e = ea + tid; e < eb; e += NT) {
-                    const uint4 r = P.rec[e];
+            if (KIND == 0 || KIND == 1) {
+                auto add = [&](int e, const uint4 &r, uint32_t label) {
                     const int base = slot_of(e) * TV;
-                    for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&D[v], (w * w) * Wl[base + v]); });
-                }
-            } else if (KIND == 1) {
-                for (int e = ea + tid; e < eb; e += NT) {
-                    const uint4 r = P.rec[e];
-                    const uint32_t label = P.aux[e];
-                    const int base = slot_of(e) * TV;
-                    if (label < (uint32_t)C)
+                    if (KIND == 0)
+                        for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&D[v], (w * w) * Wl[base + v]); });
+                    else if (label < (uint32_t)C)
                         for_corners(P, r, o0, o1, o2, [&](int v, float w) {
                             atomicAdd(&D[v * C + label], (w * w) * Wl[base + v]);
                         });
+                };
+                for (int bb = ea; bb < eb; bb += NT * EB) {
+                    uint4 r[EB];
+                    uint32_t x[EB];
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) {
+                        const int e = bb + tid + j * NT;
+                        r[j].x = 0xffffffffu;
+                        x[j] = 0;
+                        if (e < eb) { r[j] = P.rec[e]; if (KIND == 1) x[j] = P.aux[e]; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < EB; ++j)
+                        if (r[j].x != 0xffffffffu) add(bb + tid + j * NT, r[j], x[j]);
                 }
             } else {
                 // lanes-per-entry: the smallest power of two >= min(C, 64)
@@ -480,7 +525,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(FuseParams P)
             const unsigned n4 = n_el >> 2;
             const float4 *map4 = reinterpret_cast<const float4 *>(P.map);
             float4 *map4w = reinterpret_cast<float4 *>(P.map);
-            constexpr int U = 7;
+            constexpr int U = MF_FU;
             for (unsigned b = 0; b < n4; b += NT * U) {
                 float4 old[U];
                 unsigned gq[U], li[U];
@@ -823,7 +868,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     int blocks = dev.cus * per_cu;
     if (blocks > P.n_tiles) blocks = P.n_tiles;
     const int kind = P.feat_kind == MF_FEAT_ONES ? 0 : (P.feat_kind == MF_FEAT_DENSE_F32 ? 2 : 1);
-    void (*kern)(FuseParams);
+    void (*kern)(TileParams);
     if (nt <= 64) kern = kind == 0 ? fuse_tiles_kernel<0, 64> : kind == 1 ? fuse_tiles_kernel<1, 64> : fuse_tiles_kernel<2, 64>;
     else if (nt <= 256) kern = kind == 0 ? fuse_tiles_kernel<0, 256> : kind == 1 ? fuse_tiles_kernel<1, 256> : fuse_tiles_kernel<2, 256>;
     else kern = kind == 0 ? fuse_tiles_kernel<0, 1024> : kind == 1 ? fuse_tiles_kernel<1, 1024> : fuse_tiles_kernel<2, 1024>;
@@ -832,7 +877,12 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (stamps && kind == 1 && nt <= 256 && nt > 64) kern = fuse_tiles_kernel<1, 256, true>;
     if (stamps) { unsigned long long z[8] = {}; MF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z))); }
     MF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, P);
+    TileParams T;
+    T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = P.C; T.map = P.map; T.feat = P.feat;
+    T.G = P.G; T.iw = P.iw; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2; T.nt1 = P.nt1; T.nt2 = P.nt2;
+    T.n_tiles = P.n_tiles; T.magicC = P.magicC; T.gc = P.gc; T.vec4 = P.vec4; T.cursor = P.cursor;
+    T.ticket = P.ticket; T.rec = P.rec; T.aux = P.aux;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);
     MF_LAUNCH_CHECK("fuse_tiles_kernel");
     prof_mark(4, st);
     if (g_profile && g_ev_ready && g_prof_calls < PROF_CALLS) ++g_prof_calls;
