@@ -62,7 +62,8 @@ struct FuseParams {
     // workspace
     int *cursor;               // [n_keys + 1]
     int *block_sums;
-    int *ticket;
+    int *ticket;               // [1 + TILE_CLASSES]
+    int *active;               // [TILE_CLASSES][n_tiles]
     uint4 *rec;
     uint32_t *aux;
 };
@@ -77,9 +78,10 @@ struct TileParams {
     int s0, s1, s2;
     int nt1, nt2, n_tiles;
     unsigned magicC;
-    int gc, vec4;
+    int gc, vec4, fx_shift;
     const int *cursor;
     int *ticket;
+    const int *active;
     const uint4 *rec;
     const uint32_t *aux;
 };
@@ -283,6 +285,42 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int *data, int
 }
 
 // ----------------------------------------------------------------------------
+// work list: the non-empty tiles, heaviest class first
+// ----------------------------------------------------------------------------
+// ticket[0] = work counter of the tile kernel, ticket[1 + c] = tiles in class c.
+// Class 0 holds the tiles with the most entries; the tile kernel walks class 0,
+// 1, 2, 3 in that order so the long tiles start first and the tail is short.
+constexpr int TILE_CLASSES = 4;
+
+__device__ __forceinline__ int tile_class(int n)
+{
+#ifdef MF_ONE_CLASS
+    return 0;
+#else
+    return n >= 8192 ? 0 : n >= 2048 ? 1 : n >= 512 ? 2 : 3;
+#endif
+}
+
+__global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
+                                                        int n_tiles, int G, int *ticket, int *active)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    int n = 0;
+    if (t < n_tiles) n = cursor[(t + 1) * G] - cursor[t * G];
+    const int cls = tile_class(n);
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < TILE_CLASSES; ++c) {
+        const bool mine = n > 0 && cls == c;
+        const unsigned long long m = __ballot(mine);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&ticket[1 + c], __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (mine) active[c * n_tiles + base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    }
+}
+
+// ----------------------------------------------------------------------------
 // tile kernel
 // ----------------------------------------------------------------------------
 constexpr int MAX_GROUPS = 256;
@@ -333,6 +371,23 @@ __device__ unsigned long long g_stamps[8];
 #ifndef MF_FU
 #define MF_FU 4
 #endif
+// LDS float add.  ds_add_f32 costs ~80 ns per wave instruction on gfx950 whatever the
+// address pattern; one compare-and-swap round trip on the bit pattern costs ~11 ns when the
+// lanes of a wave hit distinct words.  Try the swap once, and let only the lanes that lost a
+// race (same word hit twice) take the hardware float atomic.
+__device__ __forceinline__ void lds_add_f32(float *p, float x)
+{
+    unsigned *u = reinterpret_cast<unsigned *>(p);
+    const unsigned seen = *u;
+    const unsigned prev = atomicCAS(u, seen, __float_as_uint(__uint_as_float(seen) + x));
+    if (prev != seen) atomicAdd(p, x);
+}
+
+__device__ __forceinline__ float klow(const unsigned long long *W64, int i)
+{
+    return reinterpret_cast<const float *>(W64 + i)[0];
+}
+
 constexpr int EB = MF_EB;                  // entries a thread keeps in flight / in registers per batch
 constexpr int MAX_CHUNK = 16;          // frames whose W / S2 accumulators are live at once
 constexpr float RESCALE_BELOW = 9.094947e-13f;   // 2^-40: fold the lazy decay into the deltas below this
@@ -368,29 +423,86 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     const int sv = P.s0 + P.s1 + P.s2;
     const int TV = 1 << sv;
     const int GC = P.gc;
-    float *D = smem;                               // [TV][C] accumulated deltas (in units of s)
-    float *Wl = D + (size_t)TV * C;                // [GC][TV]  W_f, then k_f
-    float *Sl = Wl + (size_t)GC * TV;              // [GC][TV]  S2_f
-    float *sc = Sl + (size_t)GC * TV;              // [TV] s: decay not yet folded into D
+    // W_f and S2_f are accumulated as 64-bit FIXED-POINT integers: gfx950's LDS float atomic
+    // (ds_add_f32) retires ~0.33 lanes/clk/CU, ds_add_u64 5.9 (tools/micro/lds_atomic_bench.hip),
+    // and integer sums are exact and order independent.  After pass 2 the low word of a W slot
+    // holds k_f as a float.
+    unsigned long long *W64 = reinterpret_cast<unsigned long long *>(smem);   // [GC][TV]
+    unsigned long long *S64 = W64 + (size_t)GC * TV;                           // [GC][TV]
+    float *D = reinterpret_cast<float *>(S64 + (size_t)GC * TV);   // [TV][C] accumulated deltas (in units of s)
+    float *sc = D + (size_t)TV * C;                // [TV] s: decay not yet folded into D
     float *osc = sc + TV;                          // [TV] prod a_f: factor of the old map value
-    int *offs = (int *)(osc + TV);                 // [MAX_GROUPS + 1] bucket starts of this tile
-    int *cb = offs + MAX_GROUPS + 1;               // [MAX_CHUNK + 1] entry offsets of the chunk's frames
-    int *misc = cb + MAX_CHUNK + 1;                // [0] ticket, [1] non-empty frame count
-    unsigned short *ne = (unsigned short *)(misc + 2);   // [MAX_GROUPS] non-empty frames, ascending
+    int *offs2 = (int *)(osc + TV);                // [2][MAX_GROUPS + 1] bucket starts: this tile / next tile
+    int *cb = offs2 + 2 * (MAX_GROUPS + 1);        // [MAX_CHUNK + 1] entry offsets of the chunk's frames
+    int *misc = cb + MAX_CHUNK + 1;                // [0] first tile, [1] non-empty frame count, [2] next tile
+    unsigned short *ne = (unsigned short *)(misc + 4);   // [MAX_GROUPS] non-empty frames, ascending
     unsigned char *touched = (unsigned char *)(ne + MAX_GROUPS);   // [TV]
     const int G = P.G;
     const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
     const unsigned n_el = (unsigned)TV * (unsigned)C;
+    const float fx_scale = __uint_as_float((unsigned)(127 + P.fx_shift) << 23);    // 2^shift
+    const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);      // 2^-shift
 
-    for (;;) {
-        if (tid == 0) misc[0] = atomicAdd(P.ticket, 1);
-        __syncthreads();
-        const int tile = misc[0];
-        if (tile >= P.n_tiles) break;
-        const int kb = tile * G;
-        for (int g = tid; g <= G; g += NT) offs[g] = (kb + g > 0) ? P.cursor[kb + g - 1] : 0;
-        __syncthreads();
-        if (offs[0] == offs[G]) { __syncthreads(); MF_STAMP(0) continue; }
+    // The work list is walked with a ticket counter.  Everything the NEXT tile needs before
+    // its first pass (ticket, tile id, bucket offsets: three dependent global round trips)
+    // is fetched while the current tile is being processed.
+    int ccount[TILE_CLASSES];
+#pragma unroll
+    for (int c = 0; c < TILE_CLASSES; ++c) ccount[c] = P.ticket[1 + c];
+    auto resolve = [&](int idx) {          // ticket -> (class, position) -> tile id, -1 past the end
+        int tile_id = -1;
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) {
+            if (tile_id < 0 && idx >= 0 && idx < ccount[c]) tile_id = P.active[c * P.n_tiles + idx];
+            idx -= ccount[c];
+        }
+        return tile_id;
+    };
+    constexpr int OPT = (MAX_GROUPS + 1 + 63) / 64;     // offsets a thread may have to fetch (NT >= 64)
+    auto load_offs = [&](int t, int (&o)[OPT]) {
+        const int kb = t * G;
+#pragma unroll
+        for (int q = 0; q < OPT; ++q) {
+            const int g = tid + q * NT;
+            o[q] = (g <= G && kb + g > 0) ? P.cursor[kb + g - 1] : 0;
+        }
+    };
+    auto store_offs = [&](int *dst, const int (&o)[OPT]) {
+#pragma unroll
+        for (int q = 0; q < OPT; ++q) {
+            const int g = tid + q * NT;
+            if (g <= G) dst[g] = o[q];
+        }
+    };
+    if (tid == 0) misc[0] = resolve(atomicAdd(P.ticket, 1));
+    __syncthreads();
+    int tile = misc[0];
+    if (tile >= 0) {
+        int o[OPT];
+        load_offs(tile, o);
+        store_offs(offs2, o);
+    }
+    __syncthreads();
+    int buf = 0;
+    // first EB entries per thread of the tile's first bucket range, fetched one tile ahead
+    uint4 pre[EB];
+    auto prefetch_entries = [&](const int *o) {
+        const int ta = o[0], tb = o[G];
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            const int e = ta + tid + j * NT;
+            pre[j].x = 0xffffffffu;
+            if (e < tb) pre[j] = P.rec[e];
+        }
+    };
+    if (tile >= 0) prefetch_entries(offs2);
+
+    while (tile >= 0) {
+        int idx_next = -1;
+        if (tid == 0) idx_next = atomicAdd(P.ticket, 1);       // consumed after pass 1
+        int onext[OPT];
+        int tile_next = -1;
+        const int *offs = offs2 + buf * (MAX_GROUPS + 1);
         MF_STAMP(0)
         const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
         const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
@@ -415,10 +527,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 
         for (int c0 = 0; c0 < n_ne; c0 += GC) {
             const int nc = min(GC, n_ne - c0);
-            for (int i = tid; i < nc * TV; i += NT) {
-                const int j = i >> sv, v = i & (TV - 1);
-                Wl[j * TV + v] = 0.0f; Sl[j * TV + v] = 0.0f;
-            }
+            for (int i = tid; i < nc * TV; i += NT) { W64[i] = 0ull; S64[i] = 0ull; }
             if (tid <= nc) cb[tid] = tid < nc ? offs[ne[c0 + tid]] : offs[ne[c0 + nc - 1] + 1];
             __syncthreads();
             MF_STAMP(2)
@@ -430,21 +539,37 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             // before the first use (memory-level parallelism: one workgroup per CU).
             for (int bb = ea; bb < eb; bb += NT * EB) {
                 uint4 r[EB];
+                if (c0 == 0 && bb == ea) {
 #pragma unroll
-                for (int j = 0; j < EB; ++j) {
-                    const int e = bb + tid + j * NT;
-                    r[j].x = 0xffffffffu;
-                    if (e < eb) r[j] = P.rec[e];
+                    for (int j = 0; j < EB; ++j) {       // fetched while the previous tile was finishing
+                        r[j] = pre[j];
+                        if (bb + tid + j * NT >= eb) r[j].x = 0xffffffffu;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) {
+                        const int e = bb + tid + j * NT;
+                        r[j].x = 0xffffffffu;
+                        if (e < eb) r[j] = P.rec[e];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < EB; ++j)
                     if (r[j].x != 0xffffffffu) {
                         const int base = slot_of(bb + tid + j * NT) * TV;
                         for_corners(P, r[j], o0, o1, o2, [&](int v, float w) {
-                            atomicAdd(&Wl[base + v], w); atomicAdd(&Sl[base + v], w * w);
+#if defined(MF_ABL_NOATOM)
+                            asm volatile("" ::"v"(v), "v"(w), "v"(base));      // ablation: no LDS atomics
+#elif defined(MF_ABL_PLAINST)
+                            W64[base + v] = (unsigned long long)(w * fx_scale); S64[base + v] = 1;   // ablation: plain LDS stores
+#else
+                            atomicAdd(&W64[base + v], (unsigned long long)(w * fx_scale));
+                            atomicAdd(&S64[base + v], (unsigned long long)((w * w) * fx_scale));
+#endif
                         });
                     }
             }
+            if (c0 == 0 && tid == 0) misc[2] = resolve(idx_next);
             __syncthreads();
             MF_STAMP(3)
             // pass 2: per voxel, frames in order: s *= a_f, k_f = g_f / s
@@ -452,16 +577,18 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                 float s = sc[v], o = osc[v];
                 bool any = false;
                 for (int j = 0; j < nc; ++j) {
-                    const float Wv = Wl[j * TV + v];
-                    if (Wv > 0.0f) {
+                    const unsigned long long wq = W64[j * TV + v];
+                    if (wq != 0ull) {
+                        const float Wv = (float)wq * fx_inv;
+                        const float S2 = (float)S64[j * TV + v] * fx_inv;
                         const float rW = __builtin_amdgcn_rcpf(Wv);
-                        const float a = 1.0f - P.iw * (Sl[j * TV + v] * rW);
+                        const float a = 1.0f - P.iw * (S2 * rW);
                         o *= a; s *= a;
                         if (!(s >= RESCALE_BELOW)) {
                             for (int c = 0; c < C; ++c) D[v * C + c] *= s;
                             s = 1.0f;
                         }
-                        Wl[j * TV + v] = P.iw * rW * __builtin_amdgcn_rcpf(s);
+                        reinterpret_cast<float *>(&W64[j * TV + v])[0] = P.iw * rW * __builtin_amdgcn_rcpf(s);
                         any = true;
                     }
                 }
@@ -469,15 +596,19 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             }
             __syncthreads();
             MF_STAMP(4)
+            if (c0 == 0) {
+                tile_next = misc[2];
+                if (tile_next >= 0) load_offs(tile_next, onext);      // in flight during pass 3
+            }
             // pass 3: D += k_f * w^2 * feat
             if (KIND == 0 || KIND == 1) {
                 auto add = [&](int e, const uint4 &r, uint32_t label) {
                     const int base = slot_of(e) * TV;
                     if (KIND == 0)
-                        for_corners(P, r, o0, o1, o2, [&](int v, float w) { atomicAdd(&D[v], (w * w) * Wl[base + v]); });
+                        for_corners(P, r, o0, o1, o2, [&](int v, float w) { lds_add_f32(&D[v], (w * w) * klow(W64, base + v)); });
                     else if (label < (uint32_t)C)
                         for_corners(P, r, o0, o1, o2, [&](int v, float w) {
-                            atomicAdd(&D[v * C + label], (w * w) * Wl[base + v]);
+                            lds_add_f32(&D[v * C + label], (w * w) * klow(W64, base + v));
                         });
                 };
                 for (int bb = ea; bb < eb; bb += NT * EB) {
@@ -505,14 +636,17 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                     const float *f = (const float *)P.feat + (size_t)P.aux[e] * C;
                     const int base = slot_of(e) * TV;
                     for_corners(P, r, o0, o1, o2, [&](int v, float w) {
-                        const float q = (w * w) * Wl[base + v];
-                        for (int c = sub; c < C; c += lpe) atomicAdd(&D[v * C + c], q * f[c]);
+                        const float q = (w * w) * klow(W64, base + v);
+                        for (int c = sub; c < C; c += lpe) lds_add_f32(&D[v * C + c], q * f[c]);
                     });
                 }
             }
+            if (c0 == 0 && tile_next >= 0) store_offs(offs2 + (buf ^ 1) * (MAX_GROUPS + 1), onext);
             __syncthreads();
             MF_STAMP(5)
         }
+
+        if (tile_next >= 0) prefetch_entries(offs2 + (buf ^ 1) * (MAX_GROUPS + 1));   // lands during the final pass
 
         // final pass: every touched voxel is read, combined and written once, with all of a
         // thread's loads in flight before the first store (one workgroup per CU: the loop is
@@ -591,6 +725,8 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
         }
         __syncthreads();
         MF_STAMP(6)
+        tile = tile_next;
+        buf ^= 1;
     }
 }
 
@@ -681,8 +817,8 @@ static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
 {
     int nt_unused;
     if (tile_override(s0, s1, s2, nt_unused)) return;
-    const size_t budget = 156 * 1024 - 32 * 1024 - 4 * (MAX_GROUPS + 32) - 2 * MAX_GROUPS;
-    size_t per_voxel = (size_t)g->channels * 4 + 8 + 1;
+    const size_t budget = 158 * 1024 - 8 * (MAX_GROUPS + 32) - 2 * MAX_GROUPS;
+    size_t per_voxel = (size_t)g->channels * 4 + 8 + 1 + 4 * 16;      // deltas, scales, flag, >= 4 frames of W/S2
     unsigned tv = (unsigned)(budget / per_voxel);
     if (tv < 1) tv = 1;
     if (tv > 1024) tv = 1024;
@@ -694,9 +830,20 @@ static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
     s0 = rem - s1;
 }
 
-static int chunk_frames(int sv, int G)
+static size_t tile_lds_fixed(int C, int sv)
 {
-    int gc = (32 * 1024) / ((1 << sv) * 8);      // W + S2 accumulators stay within 32 KB
+    const size_t TV = (size_t)1 << sv;
+    return TV * C * 4 + TV * 8 + 2 * (MAX_GROUPS + 1) * 4 + (MAX_CHUNK + 1) * 4 + 4 * 4 + MAX_GROUPS * 2 + TV + 16;
+}
+
+// frames per chunk: what fits next to the tile's deltas, at most 64 KB of accumulators
+static int chunk_frames(int C, int sv, int G)
+{
+    const size_t per_slot = ((size_t)1 << sv) * 16;
+    const size_t fixed = tile_lds_fixed(C, sv);
+    size_t avail = fixed + per_slot <= 160 * 1024 ? 160 * 1024 - fixed : per_slot;
+    if (avail > 64 * 1024) avail = 64 * 1024;
+    int gc = (int)(avail / per_slot);
     if (g_gc_override > 0) gc = g_gc_override;
     if (gc > MAX_CHUNK) gc = MAX_CHUNK;
     if (gc > G) gc = G;
@@ -706,13 +853,11 @@ static int chunk_frames(int sv, int G)
 
 static size_t tile_lds_bytes(int C, int sv, int gc)
 {
-    const size_t TV = (size_t)1 << sv;
-    return TV * C * 4 + (size_t)gc * TV * 8 + TV * 8 + (MAX_GROUPS + 1) * 4 + (MAX_CHUNK + 1) * 4 + 2 * 4 +
-           MAX_GROUPS * 2 + TV + 16;
+    return tile_lds_fixed(C, sv) + (size_t)gc * ((size_t)1 << sv) * 16;
 }
 
 struct Layout {
-    size_t cursor, block_sums, ticket, rec, aux, total;
+    size_t cursor, block_sums, ticket, active, rec, aux, total;
     int n_keys, n_scan_blocks;
     long long cap;
 };
@@ -733,6 +878,7 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
     L.cursor = off; off = align_up(off + (size_t)(n_keys + 1) * 4, 256);
     L.block_sums = off; off = align_up(off + (size_t)L.n_scan_blocks * 4, 256);
     L.ticket = off; off = align_up(off + 256, 256);
+    L.active = off; off = align_up(off + (size_t)(n_keys / G) * TILE_CLASSES * 4, 256);
     L.rec = off; off = align_up(off + (size_t)cap * 16, 256);
     L.aux = off; off = align_up(off + (size_t)cap * 4, 256);
     L.total = off;
@@ -827,6 +973,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     P.cursor = (int *)(ws + L.cursor);
     P.block_sums = (int *)(ws + L.block_sums);
     P.ticket = (int *)(ws + L.ticket);
+    P.active = (int *)(ws + L.active);
     P.rec = (uint4 *)(ws + L.rec);
     P.aux = (uint32_t *)(ws + L.aux);
     P.n_tiles = P.nt0 * P.nt1 * P.nt2;
@@ -834,7 +981,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
 
     prof_mark(0, st);
     // cursor .. ticket are contiguous: one memset
-    MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, L.rec - L.cursor, st));
+    MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, L.active - L.cursor, st));
     const unsigned bin_blocks = (unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS);
     hipLaunchKernelGGL(count_kernel<FRONT>, dim3(bin_blocks), dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
@@ -845,13 +992,16 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     hipLaunchKernelGGL(scan_apply_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
                        P.cursor, P.n_keys + 1, (const int *)P.block_sums);
     MF_LAUNCH_CHECK("scan_apply_kernel");
+    hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
+                       P.n_tiles, P.G, P.ticket, P.active);
+    MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, dim3(bin_blocks), dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
     prof_mark(3, st);
 
     const int sv = P.s0 + P.s1 + P.s2;
-    P.gc = chunk_frames(sv, P.G);
+    P.gc = chunk_frames(P.C, sv, P.G);
     P.vec4 = ((uintptr_t)P.map % 16 == 0) && ((P.C << P.s2) % 4 == 0) && (P.size2 % (1 << P.s2) == 0) &&
              ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34)) && getenv("MF_NO_VEC4") == nullptr;
     const size_t lds = tile_lds_bytes(P.C, sv, P.gc);
@@ -873,15 +1023,22 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     else if (nt <= 256) kern = kind == 0 ? fuse_tiles_kernel<0, 256> : kind == 1 ? fuse_tiles_kernel<1, 256> : fuse_tiles_kernel<2, 256>;
     else kern = kind == 0 ? fuse_tiles_kernel<0, 1024> : kind == 1 ? fuse_tiles_kernel<1, 1024> : fuse_tiles_kernel<2, 1024>;
     static const bool stamps = getenv("MF_STAMPS") != nullptr;
-    if (stamps && kind == 1 && nt > 256) kern = fuse_tiles_kernel<1, 1024, true>;
-    if (stamps && kind == 1 && nt <= 256 && nt > 64) kern = fuse_tiles_kernel<1, 256, true>;
+    if (stamps && nt > 256) kern = kind == 0 ? fuse_tiles_kernel<0, 1024, true> : kind == 1 ? fuse_tiles_kernel<1, 1024, true> : fuse_tiles_kernel<2, 1024, true>;
+    if (stamps && nt <= 256 && nt > 64) kern = kind == 0 ? fuse_tiles_kernel<0, 256, true> : kind == 1 ? fuse_tiles_kernel<1, 256, true> : fuse_tiles_kernel<2, 256, true>;
     if (stamps) { unsigned long long z[8] = {}; MF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z))); }
     MF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     TileParams T;
     T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = P.C; T.map = P.map; T.feat = P.feat;
     T.G = P.G; T.iw = P.iw; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2; T.nt1 = P.nt1; T.nt2 = P.nt2;
     T.n_tiles = P.n_tiles; T.magicC = P.magicC; T.gc = P.gc; T.vec4 = P.vec4; T.cursor = P.cursor;
-    T.ticket = P.ticket; T.rec = P.rec; T.aux = P.aux;
+    // fixed-point fraction bits of the W / S2 sums: the per-voxel, per-frame sum of weights is
+    // below (points per group) * (1 + 1e-9), and must stay below 2^63
+    {
+        long long per_group = P.G > 1 ? (P.n_points + P.G - 1) / P.G : P.n_points;
+        int bits = 1; while ((1ll << bits) <= per_group) ++bits;
+        T.fx_shift = 62 - bits; if (T.fx_shift > 50) T.fx_shift = 50;
+    }
+    T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);
     MF_LAUNCH_CHECK("fuse_tiles_kernel");
     prof_mark(4, st);
