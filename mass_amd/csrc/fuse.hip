@@ -378,9 +378,18 @@ __device__ unsigned long long g_stamps[8];
 __device__ __forceinline__ void lds_add_f32(float *p, float x)
 {
     unsigned *u = reinterpret_cast<unsigned *>(p);
+#ifdef MF_CAS_LOOP
+    unsigned seen = *u, prev;
+    for (;;) {
+        prev = atomicCAS(u, seen, __float_as_uint(__uint_as_float(seen) + x));
+        if (prev == seen) break;
+        seen = prev;
+    }
+#else
     const unsigned seen = *u;
     const unsigned prev = atomicCAS(u, seen, __float_as_uint(__uint_as_float(seen) + x));
     if (prev != seen) atomicAdd(p, x);
+#endif
 }
 
 __device__ __forceinline__ float klow(const unsigned long long *W64, int i)
@@ -794,9 +803,9 @@ __global__ void unproject_bin_kernel(FuseParams P, BinOut o)
 // ----------------------------------------------------------------------------
 static int ilog2_floor(unsigned x) { int l = 0; while ((2u << l) <= x) ++l; return l; }
 
-// Tile extents: the largest power-of-two voxel count whose LDS image
-// (C floats of map + W + S2 + flag + list per voxel) fits ~140 KB, capped at
-// 1024 voxels; z gets up to 8 (16 for >= 1024 voxels) so that HBM runs stay long.
+// Tile extents: the largest power-of-two voxel count whose LDS image (C floats of
+// deltas + scales + flag + four frames of 64-bit W/S2 accumulators per voxel) fits the
+// CU's LDS, capped at 512 voxels (8 x 8 x 8); z gets up to 8 so that HBM runs stay long.
 // Tuning override for experiments: MF_TILE="s0 s1 s2 threads" (log2 extents).
 static int g_gc_override = -1;
 static bool tile_override(int &s0, int &s1, int &s2, int &nt)
@@ -821,9 +830,9 @@ static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
     size_t per_voxel = (size_t)g->channels * 4 + 8 + 1 + 4 * 16;      // deltas, scales, flag, >= 4 frames of W/S2
     unsigned tv = (unsigned)(budget / per_voxel);
     if (tv < 1) tv = 1;
-    if (tv > 1024) tv = 1024;
+    if (tv > 512) tv = 512;       // larger tiles starve the chip when a scene concentrates on few tiles
     int sv = ilog2_floor(tv);
-    s2 = sv >= 10 ? 4 : 3;
+    s2 = 3;
     if (s2 > sv) s2 = sv;
     const int rem = sv - s2;
     s1 = (rem + 1) / 2;
@@ -1008,7 +1017,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     const DeviceInfo &dev = device_info();
     if (lds > (size_t)dev.lds_per_cu)
         return fail(MF_ERR_INVALID, "tile needs %zu bytes of LDS, device has %d", lds, dev.lds_per_cu);
-    int nt = ((size_t)(1 << sv) * P.C >= 8192) ? 1024 : 256;
+    int nt = sv >= 9 ? 1024 : sv >= 7 ? 512 : 256;     // heavy tiles are bound by threads per tile
     { int a, b, c; tile_override(a, b, c, nt); }
     int per_cu = (int)((size_t)dev.lds_per_cu / lds);
     if (per_cu > 16) per_cu = 16;
