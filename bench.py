@@ -14,7 +14,6 @@ scaling); the only collective is the final metrics all-reduce.
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -95,19 +94,14 @@ def cpu_baseline(frames, n):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    from mass_amd import distributed as D
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    rank, world, local_rank = D.init_from_env(backend="nccl")      # nccl == RCCL on ROCm
+    args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
     from mass_amd import _lib
     from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
@@ -127,9 +121,8 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -149,18 +142,15 @@ def main():
     _lib.check(_lib.lib.mf_profile_enable(0))
     gpu_ms = ev0.elapsed_time(ev1)
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    wall_max = D.max_over_ranks(wall)
 
     # ---- algorithmic bytes of one step: sum_f H*W*(4+1) + T_f*C*4*2 ------------
     T, valid_pts = touched_per_frame(lay, poses, depth)
     alg_bytes = sum(H * W * (4 + 1) + Tf * C * 4 * 2 for Tf in T)
-    metrics = torch.tensor([args.batch * args.steps, valid_pts * args.steps, sum(T) * args.steps,
-                            float(lay.data.abs().sum(dtype=torch.float64))], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)        # the one RCCL collective of the run
+    # the one data collective of the run: SUM all-reduce of the per-rank counters (RCCL)
+    metrics = D.reduce_metrics(dict(frames=args.batch * args.steps, valid_points=valid_pts * args.steps,
+                                    touched_voxels=sum(T) * args.steps,
+                                    map_abs_sum=float(lay.data.abs().sum(dtype=torch.float64))))
 
     if rank == 0:
         frames_total = args.batch * args.steps * world
@@ -195,8 +185,7 @@ def main():
                                                                    "fuse_tiles": fuse_ms}},
             "touched_voxels_per_frame_mean": float(np.mean(T)),
             "gpu_ms_total": gpu_ms,
-            "metrics_allreduce": {"frames": metrics[0].item(), "valid_points": metrics[1].item(),
-                                  "touched_voxels": metrics[2].item(), "map_abs_sum": metrics[3].item()},
+            "metrics_allreduce": metrics,
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, _ = cpu_baseline(frames, args.cpu_frames)
@@ -204,8 +193,8 @@ def main():
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        D.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
