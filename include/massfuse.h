@@ -145,6 +145,18 @@ MF_API int mf_update_feature_map(const mf_grid *grid, int64_t n,
                           const void *feat, int32_t feat_kind, float interpolation_weight,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- whole-map reductions used by the callers of the layers ----- */
+
+/* navigation_policy.py:208-218: out[y*size1 + x] = 1 if any voxel z in [z0, z1) of column
+ * (y, x) has sum_c |map| > threshold, else 0 (uint8, device).  The caller turns it into the
+ * navigable image and applies the 2-D padding (:220-221). */
+MF_API int mf_column_occupied(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels,
+                              int32_t z0, int32_t z1, float threshold, uint8_t *out, void *stream);
+
+/* agent.py:330-331,391-392: out[y][x][c] = max over z of map[y][x][z][c] (data.amax(dim=2)). */
+MF_API int mf_amax_z(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels, float *out,
+                     void *stream);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 
 /* Stage timing of the fuse pipeline for the roofline report (bench.py): after

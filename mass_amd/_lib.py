@@ -58,6 +58,9 @@ SIGNATURES = {
     "mf_update_feature_map": (ctypes.c_int, [ctypes.POINTER(MfGrid), c_int64, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float,
                                              c_void_p, c_size_t, c_void_p]),
+    "mf_column_occupied": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+                                          c_void_p, c_void_p]),
+    "mf_amax_z": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mf_profile_enable": (ctypes.c_int, [c_int32]),
     "mf_profile_read": (ctypes.c_int, [c_int32, c_void_p]),
     "mf_pairwise_distance": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,

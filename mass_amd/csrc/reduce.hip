@@ -1,0 +1,106 @@
+// reduce.hip — whole-map reductions the callers of the map layers run every few steps
+// (SURVEY 8 f2), as single-pass HBM-streaming kernels over the [y][x][z][C] map.
+//
+//   mf_column_occupied  /root/reference/mass/navigation_policy.py:208-218
+//       navigable = logical_not((norm(data, p=1, dim=3) > thr)[:, :, slice].any(dim=2))
+//       (this kernel produces the `any` mask; the 2-D max_pool2d padding of :220-221 stays
+//        in torch on the tiny [H, W] image)
+//   mf_amax_z           /root/reference/agent.py:330-331, 391-392:  data.amax(dim=2)
+//
+// A (y, x) column of the map is one contiguous run of D*C floats, so both kernels give a
+// workgroup one column and read it with consecutive lanes on consecutive floats.
+#include "common.h"
+
+namespace mf {
+
+constexpr int RT = 256;
+
+// out[col] = 1 if any voxel z in [z0, z1) of the column has sum_c |m| > thr
+__global__ __launch_bounds__(RT) void column_occupied_kernel(const float *__restrict__ map, int D, int C, int z0,
+                                                              int z1, float thr, int zchunk, uint8_t *out)
+{
+    extern __shared__ float col[];          // [zchunk][C]
+    __shared__ int found;
+    const size_t base = (size_t)blockIdx.x * D * C;
+    if (threadIdx.x == 0) found = 0;
+    __syncthreads();
+    for (int za = z0; za < z1; za += zchunk) {
+        const int nz = min(zchunk, z1 - za);
+        const float *src = map + base + (size_t)za * C;
+        for (int i = threadIdx.x; i < nz * C; i += RT) col[i] = src[i];
+        __syncthreads();
+        for (int z = threadIdx.x; z < nz; z += RT) {
+            float s = 0.0f;
+            for (int c = 0; c < C; ++c) s += fabsf(col[z * C + c]);
+            if (s > thr) found = 1;          // benign race: every writer stores 1
+        }
+        __syncthreads();
+        if (found) break;
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (uint8_t)found;
+}
+
+// out[col][c] = max_z map[col][z][c]
+__global__ __launch_bounds__(RT) void amax_z_kernel(const float *__restrict__ map, int D, int C, float *out)
+{
+    __shared__ float part[RT];
+    const float *src = map + (size_t)blockIdx.x * D * C;
+    float *dst = out + (size_t)blockIdx.x * C;
+    if (C <= RT) {
+        // threads t < S = C * (RT / C) stride the column by S, so a thread always sees channel t % C
+        const int rep = RT / C, S = C * rep, n = D * C;
+        float m = -INFINITY;
+        if ((int)threadIdx.x < S)
+            for (int e = threadIdx.x; e < n; e += S) m = fmaxf(m, src[e]);
+        part[threadIdx.x] = m;
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            float r = part[threadIdx.x];
+            for (int k = 1; k < rep; ++k) r = fmaxf(r, part[threadIdx.x + k * C]);
+            dst[threadIdx.x] = r;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += RT) {
+            float m = -INFINITY;
+            for (int z = 0; z < D; ++z) m = fmaxf(m, src[(size_t)z * C + c]);
+            dst[c] = m;
+        }
+    }
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" {
+
+int mf_column_occupied(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels, int32_t z0,
+                       int32_t z1, float threshold, uint8_t *out, void *stream)
+{
+    if (!map || !out) return fail(MF_ERR_INVALID, "NULL pointer");
+    if (size0 < 1 || size1 < 1 || size2 < 1 || channels < 1) return fail(MF_ERR_INVALID, "bad map shape");
+    if (z0 < 0) z0 = 0;
+    if (z1 > size2) z1 = size2;
+    if (z1 < z0) z1 = z0;
+    int zchunk = 8192 / channels;
+    if (zchunk < 1) zchunk = 1;
+    if (zchunk > size2) zchunk = size2;
+    const size_t lds = (size_t)zchunk * channels * 4;
+    if (lds > 60 * 1024) return fail(MF_ERR_INVALID, "channels = %d too large for the column kernel", channels);
+    hipLaunchKernelGGL(column_occupied_kernel, dim3((unsigned)(size0 * size1)), dim3(RT), lds, (hipStream_t)stream,
+                       map, size2, channels, z0, z1, threshold, zchunk, out);
+    MF_LAUNCH_CHECK("column_occupied_kernel");
+    return MF_OK;
+}
+
+int mf_amax_z(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels, float *out, void *stream)
+{
+    if (!map || !out) return fail(MF_ERR_INVALID, "NULL pointer");
+    if (size0 < 1 || size1 < 1 || size2 < 1 || channels < 1) return fail(MF_ERR_INVALID, "bad map shape");
+    hipLaunchKernelGGL(amax_z_kernel, dim3((unsigned)(size0 * size1)), dim3(RT), 0, (hipStream_t)stream, map, size2,
+                       channels, out);
+    MF_LAUNCH_CHECK("amax_z_kernel");
+    return MF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+"""navigable_area / amax over z on the GPU against the reference's recorded
+outputs and against the same torch ops on the CPU at larger sizes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as functional
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_navigable(data, padding, depth_slice, thr):
+    nav = torch.norm(data, p=1, dim=3) > thr
+    if depth_slice is not None:
+        nav = nav[:, :, depth_slice]
+    nav = torch.logical_not(nav.any(dim=2)).to(dtype=data.dtype)
+    return 1 - functional.max_pool2d(1 - nav.unsqueeze(0), 2 * padding + 1, stride=1, padding=padding).squeeze(0)
+
+
+def test_golden_navigable_and_amax(device):
+    from mass_amd.utils.reductions import navigable_area, amax_z
+    tf = load_golden("transforms_small.npz")
+    data = torch.tensor(tf["data"]).to(device)
+    for thr in (0.0, 0.5):
+        got = navigable_area(data, padding=2, depth_slice=slice(2, 9), obstacle_threshold=thr)
+        assert np.array_equal(got.cpu().numpy(), tf[f"navigable_thr{thr}"])
+    assert np.array_equal(amax_z(data).cpu().numpy(), tf["amax_z"])
+
+
+@pytest.mark.parametrize("shape", [(64, 48, 40, 1), (33, 65, 96, 54), (16, 16, 7, 300), (40, 40, 256, 3)])
+def test_against_torch_cpu(device, shape):
+    from mass_amd.utils.reductions import navigable_area, amax_z, column_occupied
+    g = torch.Generator().manual_seed(sum(shape))
+    data = torch.rand(*shape, generator=g) * (torch.rand(*shape[:3], 1, generator=g) < 0.02)
+    d = data.to(device)
+    assert torch.equal(amax_z(d).cpu(), data.amax(dim=2))
+    for sl, thr, pad in ((None, 0.0, 3), (slice(4, 32), 0.0, 1), (slice(1, 5), 0.3 * shape[3] ** 0.5, 0)):
+        assert torch.equal(navigable_area(d, pad, sl, thr).cpu(), ref_navigable(data, pad, sl, thr))
+    assert not column_occupied(torch.zeros_like(d)).any()

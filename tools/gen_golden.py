@@ -328,11 +328,52 @@ def gen_match_small():
     print("match_small: ok")
 
 
+
+
+# ---------------------------------------------------------------------------
+def gen_transforms():
+    """coordinate transforms, top_down, and the whole-map reductions the
+    callers run on the maps (navigation_policy.py:208-221 navigable_area, agent.py:330 amax)."""
+    import torch.nn.functional as functional
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    lay = ref_layer(4, origin=(-3.7501, 1.25, 0.123456), m=24, md=12)
+    lay.data.copy_(torch.rand(24, 24, 12, 4, generator=g) * (torch.rand(24, 24, 12, 1, generator=g) < 0.15))
+    out["origin_yxz"] = np.asarray((-3.7501, 1.25, 0.123456), np.float64)
+    out["data"] = np32(lay.data)
+    world = torch.cat([torch.rand(200, 3, generator=g) * 4 - 2 + torch.tensor([1.25, -3.7501, 0.12]),
+                       torch.tensor([[1.25, -3.7501, 0.123456], [100.0, 100.0, 100.0], [-100.0, -100.0, -100.0]]),
+                       torch.stack([lay.bins_x[3], lay.bins_y[5], lay.bins_z[7]]).view(1, 3)])
+    out["world"] = np32(world)
+    out["clamp_to_world"] = np32(lay.clamp_to_world(world))
+    out["world_to_map"] = lay.world_to_map(world).numpy().astype(np.int64)
+    out["world_to_map_xy"] = lay.world_to_map(world[:, :2]).numpy().astype(np.int64)
+    mapc = torch.cat([torch.rand(200, 3, generator=g) * torch.tensor([26.0, 26.0, 14.0]) - 1.0,
+                      torch.tensor([[0.0, 0.0, 0.0], [23.0, 23.0, 11.0], [5.5, 7.25, 3.0]])])
+    out["map_coords"] = np32(mapc)
+    out["clamp_to_map"] = np32(lay.clamp_to_map(mapc))
+    out["map_to_world"] = np32(lay.map_to_world(mapc))
+    out["top_down_0_8"] = np32(lay.top_down(depth_slice=slice(0, 8)))
+    out["top_down_all"] = np32(lay.top_down(depth_slice=None))
+    out["visualize"] = np.asarray(lay.visualize({}, depth_slice=slice(0, 8)), np.float32)
+    # navigable_area body (navigation_policy.py:208-221) with padding 2, slice(2, 9), thresholds 0 and 0.5
+    for thr in (0.0, 0.5):
+        nav = torch.norm(lay.data, p=1, dim=3) > thr
+        nav = nav[:, :, slice(2, 9)]
+        nav = torch.logical_not(nav.any(dim=2)).to(dtype=lay.data.dtype)
+        nav = 1 - functional.max_pool2d(1 - nav.unsqueeze(0), 2 * 2 + 1, stride=1, padding=2).squeeze(0)
+        out[f"navigable_thr{thr}"] = np32(nav)
+    out["amax_z"] = np32(lay.data.amax(dim=2))          # agent.py:330-331
+    np.savez_compressed(os.path.join(OUT, "transforms_small.npz"), **out)
+    print("transforms_small: ok")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geom", "splat", "edge", "match", "digest"]
+    which = sys.argv[1:] or ["geom", "splat", "edge", "match", "transforms", "digest"]
     if "geom" in which: gen_geom_small()
     if "splat" in which: gen_splat_small()
     if "edge" in which: gen_edge_cases()
     if "match" in which: gen_match_small()
+    if "transforms" in which: gen_transforms()
     if "digest" in which: gen_digest_480x640()
     print("all fixtures written to", OUT)
