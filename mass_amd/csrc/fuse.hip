@@ -106,8 +106,9 @@ template <int FRONT>
 __device__ __forceinline__ bool get_point(const FuseParams &P, long long idx, Point &pt, uint32_t &aux)
 {
     if (FRONT == 0) {
+        // frames are launched on blockIdx.y (point_index), so no 64-bit divide is needed here
         const int HW = P.H * P.W;
-        const int f = (int)(idx / HW);
+        const int f = blockIdx.y;
         const int pix = (int)(idx - (long long)f * HW);
         const float d = P.depth[idx];
         const float *pose = P.poses + f * 12;
@@ -135,6 +136,20 @@ __device__ __forceinline__ bool get_point(const FuseParams &P, long long idx, Po
             aux = P.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)idx : read_label(P.feat, P.feat_kind, idx);
         return ok;
     }
+}
+
+// Global point index of this thread, or -1.  Front end 0 is launched as
+// (ceil(H*W / threads), n_frames) blocks, front end 1 as a flat grid.
+template <int FRONT>
+__device__ __forceinline__ long long point_index(const FuseParams &P, int threads)
+{
+    if (FRONT == 0) {
+        const int HW = P.H * P.W;
+        const int pix = blockIdx.x * threads + threadIdx.x;
+        return pix < HW ? (long long)blockIdx.y * HW + pix : -1;
+    }
+    const long long idx = (long long)blockIdx.x * threads + threadIdx.x;
+    return idx < P.n_points ? idx : -1;
 }
 
 // The <=8 (tile, group) buckets a point's footprint overlaps.
@@ -183,15 +198,19 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
     __shared__ int hcnt[HS];
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
     __syncthreads();
-    const long long idx = (long long)blockIdx.x * BIN_THREADS + threadIdx.x;
-    if (idx < P.n_points) {
+    const long long idx = point_index<FRONT>(P, BIN_THREADS);
+    if (idx >= 0) {
         Point pt; uint32_t aux = 0;
         if (get_point<FRONT>(P, idx, pt, aux)) {
             uint32_t keys[8];
             const int n = point_keys(P, pt, keys);
             for (int i = 0; i < n; ++i) {
+#ifdef MF_ABL_COUNT_NOHASH
+                asm volatile("" ::"v"(keys[i]));
+#else
                 int rank;
                 if (hash_insert(hkey, hcnt, keys[i], rank) < 0) atomicAdd(&P.cursor[keys[i]], 1);
+#endif
             }
         }
     }
@@ -207,12 +226,12 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
     __shared__ int hcnt[HS];
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
     __syncthreads();
-    const long long idx = (long long)blockIdx.x * BIN_THREADS + threadIdx.x;
+    const long long idx = point_index<FRONT>(P, BIN_THREADS);
     Point pt; uint32_t aux = 0;
     uint32_t keys[8];
     int slot[8], rank[8];
     int n = 0;
-    if (idx < P.n_points && get_point<FRONT>(P, idx, pt, aux)) {
+    if (idx >= 0 && get_point<FRONT>(P, idx, pt, aux)) {
         n = point_keys(P, pt, keys);
         for (int i = 0; i < n; ++i) slot[i] = hash_insert(hkey, hcnt, keys[i], rank[i]);
     }
@@ -790,8 +809,8 @@ __global__ void bin_rays_kernel(Bins B, const float *__restrict__ origin, const 
 
 __global__ void unproject_bin_kernel(FuseParams P, BinOut o)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P.n_points) return;
+    const long long idx = point_index<0>(P, 256);
+    if (idx < 0) return;
     Point pt; uint32_t aux = 0;
     const bool ok = get_point<0>(P, idx, pt, aux);
     // outputs in the reference's (x, y, z) order of bin_rays
@@ -991,8 +1010,9 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     prof_mark(0, st);
     // cursor .. ticket are contiguous: one memset
     MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, L.active - L.cursor, st));
-    const unsigned bin_blocks = (unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS);
-    hipLaunchKernelGGL(count_kernel<FRONT>, dim3(bin_blocks), dim3(BIN_THREADS), 0, st, P);
+    const dim3 bin_blocks = FRONT == 0 ? dim3((unsigned)((P.H * P.W + BIN_THREADS - 1) / BIN_THREADS), (unsigned)P.n_frames)
+                                       : dim3((unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS));
+    hipLaunchKernelGGL(count_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
     prof_mark(1, st);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
@@ -1005,7 +1025,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
                        P.n_tiles, P.G, P.ticket, P.active);
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
-    hipLaunchKernelGGL(scatter_kernel<FRONT>, dim3(bin_blocks), dim3(BIN_THREADS), 0, st, P);
+    hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
     prof_mark(3, st);
 
@@ -1191,8 +1211,8 @@ int mf_unproject_bin(const mf_grid *grid, const mf_frames *frames, int64_t *ind_
     fill_frames(P, &f);
     P.G = 1;
     BinOut o = {ind_x, ind_y, ind_z, ratio_x, ratio_y, ratio_z, valid};
-    hipLaunchKernelGGL(unproject_bin_kernel, dim3((unsigned)((P.n_points + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, P, o);
+    hipLaunchKernelGGL(unproject_bin_kernel, dim3((unsigned)((P.H * P.W + 255) / 256), (unsigned)P.n_frames),
+                       dim3(256), 0, (hipStream_t)stream, P, o);
     MF_LAUNCH_CHECK("unproject_bin_kernel");
     return MF_OK;
 }

@@ -21,7 +21,7 @@ __device__ __forceinline__ int upper_bound_edges(const float *__restrict__ b, in
     if (!(p == p)) return n;
     const float b0 = b[0];
     const float step = b[1] - b0;
-    const float t = (p - b0) / step;
+    const float t = (p - b0) * __builtin_amdgcn_rcpf(step);   // a guess only: verified against the edges below
     int c;
     if (!(t >= 0.0f)) c = 0;
     else if (t >= (float)n) c = n;
