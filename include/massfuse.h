@@ -157,6 +157,29 @@ MF_API int mf_column_occupied(const float *map, int32_t size0, int32_t size1, in
 MF_API int mf_amax_z(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels, float *out,
                      void *stream);
 
+/* ---- instance extraction, SemanticProjectionLayer.find ---------- */
+
+/* cv2.findContours(RETR_LIST) + cv2.boundingRect (semantic_projection_layer.py:323-328) on
+ * a HOST uint8 image [height][width]: bounding boxes (x, y, w, h) of every outer and hole
+ * border, 8-connected foreground (Suzuki-Abe border following).  reverse_order != 0 lists
+ * the border found last first, as OpenCV does.  Returns the number of borders (which may
+ * exceed max_boxes; only max_boxes are written) or <0.  Parity unpinned (cv2 absent). */
+MF_API int mf_contour_boxes(const uint8_t *img, int32_t height, int32_t width, int32_t reverse_order,
+                            int32_t *boxes, int32_t max_boxes);
+
+/* Per-box moments of one class channel (semantic_projection_layer.py:331-357):
+ * for box b = (x, y, w, h) over all z, with m = map[y'][x'][z][category]:
+ *   out[b] = { sum m, sum m^2, sum m*cx[x'], sum m*cy[y'], sum m*cz[z] }  (5 doubles-as-floats)
+ * and, if feat != NULL, feat_out[b][j] = sum m * feat[y'][x'][z][j].
+ * map device fp32 [size0][size1][size2][channels]; cx/cy/cz device fp32 voxel-centre world
+ * coordinates per index; boxes device int32 [n_boxes][4]; feat device fp32
+ * [size0][size1][size2][feat_channels] or NULL; out device fp32 [n_boxes][5];
+ * feat_out device fp32 [n_boxes][feat_channels]. */
+MF_API int mf_roi_moments(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels,
+                          int32_t category, const float *cx, const float *cy, const float *cz,
+                          const int32_t *boxes, int32_t n_boxes, const float *feat, int32_t feat_channels,
+                          float *out, float *feat_out, void *stream);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 
 /* Stage timing of the fuse pipeline for the roofline report (bench.py): after

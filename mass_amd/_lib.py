@@ -61,6 +61,9 @@ SIGNATURES = {
     "mf_column_occupied": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
                                           c_void_p, c_void_p]),
     "mf_amax_z": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "mf_contour_boxes": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32]),
+    "mf_roi_moments": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "mf_profile_enable": (ctypes.c_int, [c_int32]),
     "mf_profile_read": (ctypes.c_int, [c_int32, c_void_p]),
     "mf_pairwise_distance": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,

@@ -138,15 +138,21 @@ __device__ __forceinline__ bool get_point(const FuseParams &P, long long idx, Po
     }
 }
 
-// Global point index of this thread, or -1.  Front end 0 is launched as
-// (ceil(H*W / threads), n_frames) blocks, front end 1 as a flat grid.
+// Global point index of this thread, or -1.  Front end 0 is launched as (patches, n_frames)
+// blocks where a 256-thread block owns a 16 x 16 pixel patch: a compact patch is a narrow
+// pencil in space, so its points fall into few map tiles (fewer distinct buckets per block =
+// fewer global atomics and longer contiguous record runs than a 256 x 1 pixel strip).
+// Front end 1 is a flat grid.
+constexpr int PATCH = 16;
+
 template <int FRONT>
 __device__ __forceinline__ long long point_index(const FuseParams &P, int threads)
 {
     if (FRONT == 0) {
-        const int HW = P.H * P.W;
-        const int pix = blockIdx.x * threads + threadIdx.x;
-        return pix < HW ? (long long)blockIdx.y * HW + pix : -1;
+        const int pw = (P.W + PATCH - 1) / PATCH;
+        const int py = blockIdx.x / pw, px = blockIdx.x - py * pw;
+        const int y = py * PATCH + (int)(threadIdx.x / PATCH), x = px * PATCH + (int)(threadIdx.x % PATCH);
+        return (y < P.H && x < P.W) ? (long long)blockIdx.y * (P.H * P.W) + y * P.W + x : -1;
     }
     const long long idx = (long long)blockIdx.x * threads + threadIdx.x;
     return idx < P.n_points ? idx : -1;
@@ -1010,7 +1016,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     prof_mark(0, st);
     // cursor .. ticket are contiguous: one memset
     MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, L.active - L.cursor, st));
-    const dim3 bin_blocks = FRONT == 0 ? dim3((unsigned)((P.H * P.W + BIN_THREADS - 1) / BIN_THREADS), (unsigned)P.n_frames)
+    const dim3 bin_blocks = FRONT == 0 ? dim3((unsigned)(((P.H + PATCH - 1) / PATCH) * ((P.W + PATCH - 1) / PATCH)), (unsigned)P.n_frames)
                                        : dim3((unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS));
     hipLaunchKernelGGL(count_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
@@ -1211,7 +1217,7 @@ int mf_unproject_bin(const mf_grid *grid, const mf_frames *frames, int64_t *ind_
     fill_frames(P, &f);
     P.G = 1;
     BinOut o = {ind_x, ind_y, ind_z, ratio_x, ratio_y, ratio_z, valid};
-    hipLaunchKernelGGL(unproject_bin_kernel, dim3((unsigned)((P.H * P.W + 255) / 256), (unsigned)P.n_frames),
+    hipLaunchKernelGGL(unproject_bin_kernel, dim3((unsigned)(((P.H + PATCH - 1) / PATCH) * ((P.W + PATCH - 1) / PATCH)), (unsigned)P.n_frames),
                        dim3(256), 0, (hipStream_t)stream, P, o);
     MF_LAUNCH_CHECK("unproject_bin_kernel");
     return MF_OK;

@@ -104,3 +104,82 @@ int mf_amax_z(const float *map, int32_t size0, int32_t size1, int32_t size2, int
 }
 
 }  // extern "C"
+
+// ----------------------------------------------------------------------------
+// per-box moments of one class channel (SemanticProjectionLayer.find)
+// ----------------------------------------------------------------------------
+namespace mf {
+
+__device__ __forceinline__ float block_sum(float v, float *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int w = 0; w < RT / 64; ++w) t += sh[w];
+    return t;
+}
+
+// one workgroup per box; voxels with m == 0 (almost all of them) cost one strided read
+__global__ __launch_bounds__(RT) void roi_moments_kernel(const float *__restrict__ map, int size1, int size2, int C,
+                                                          int category, const float *__restrict__ cx,
+                                                          const float *__restrict__ cy, const float *__restrict__ cz,
+                                                          const int *__restrict__ boxes, const float *__restrict__ feat,
+                                                          int FC, float *out, float *feat_out)
+{
+    __shared__ float sh[RT / 64];
+    __shared__ int nz_count;
+    __shared__ int nz_vox[1024];
+    __shared__ float nz_m[1024];
+    const int bx = boxes[blockIdx.x * 4], by = boxes[blockIdx.x * 4 + 1], bw = boxes[blockIdx.x * 4 + 2],
+              bh = boxes[blockIdx.x * 4 + 3];
+    const int n = bw * bh * size2;
+    float s1 = 0, s2 = 0, sx = 0, sy = 0, sz = 0;
+    for (int c = threadIdx.x; c < FC; c += RT) feat_out[(size_t)blockIdx.x * FC + c] = 0.0f;
+    for (int base = 0; base < n; base += 1024) {
+        if (threadIdx.x == 0) nz_count = 0;
+        __syncthreads();
+        for (int e = base + threadIdx.x; e < min(n, base + 1024); e += RT) {
+            const int z = e % size2, r = e / size2, x = bx + r % bw, y = by + r / bw;
+            const int vox = (y * size1 + x) * size2 + z;
+            const float m = map[(size_t)vox * C + category];
+            if (m != 0.0f) {
+                s1 += m; s2 += m * m; sx += m * cx[x]; sy += m * cy[y]; sz += m * cz[z];
+                if (feat) { const int k = atomicAdd(&nz_count, 1); nz_vox[k] = vox; nz_m[k] = m; }
+            }
+        }
+        __syncthreads();
+        if (feat)
+            for (int c = threadIdx.x; c < FC; c += RT) {
+                float acc = 0.0f;
+                for (int k = 0; k < nz_count; ++k) acc += nz_m[k] * feat[(size_t)nz_vox[k] * FC + c];
+                feat_out[(size_t)blockIdx.x * FC + c] += acc;
+            }
+        __syncthreads();
+    }
+    s1 = block_sum(s1, sh); s2 = block_sum(s2, sh); sx = block_sum(sx, sh); sy = block_sum(sy, sh);
+    sz = block_sum(sz, sh);
+    if (threadIdx.x == 0) {
+        float *o = out + (size_t)blockIdx.x * 5;
+        o[0] = s1; o[1] = s2; o[2] = sx; o[3] = sy; o[4] = sz;
+    }
+}
+
+}  // namespace mf
+
+extern "C" int mf_roi_moments(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels,
+                              int32_t category, const float *cx, const float *cy, const float *cz,
+                              const int32_t *boxes, int32_t n_boxes, const float *feat, int32_t feat_channels,
+                              float *out, float *feat_out, void *stream)
+{
+    if (n_boxes == 0) return MF_OK;
+    if (!map || !cx || !cy || !cz || !boxes || !out || n_boxes < 0) return mf::fail(MF_ERR_INVALID, "bad argument");
+    if (category < 0 || category >= channels) return mf::fail(MF_ERR_INVALID, "category %d outside [0, %d)", category, channels);
+    if (feat && (!feat_out || feat_channels < 1)) return mf::fail(MF_ERR_INVALID, "feat_out / feat_channels missing");
+    (void)size0;
+    hipLaunchKernelGGL(mf::roi_moments_kernel, dim3((unsigned)n_boxes), dim3(mf::RT), 0, (hipStream_t)stream, map, size1,
+                       size2, channels, category, cx, cy, cz, boxes, feat, feat ? feat_channels : 0, out, feat_out);
+    MF_LAUNCH_CHECK("roi_moments_kernel");
+    return MF_OK;
+}

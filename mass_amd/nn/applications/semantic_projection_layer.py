@@ -8,9 +8,25 @@ MF_FEAT_LABEL_* and the one-hot tensor is never materialised.
 """
 from typing import Any, Dict
 
+import numpy as np
 import torch
+import torch.nn.functional as functional
 
+from mass_amd import _lib
+from mass_amd._lib import lib, check, ptr, current_stream
 from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+from mass_amd.utils.reductions import amax_z
+
+
+def contour_boxes(image, reverse_order=True):
+    """Bounding boxes (x, y, w, h) of all borders of a binary image, in the order
+    cv2.findContours(RETR_LIST) lists them (host; mf_contour_boxes)."""
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = image.shape
+    cap = max(16, (h * w + 1) // 2 + 8)
+    boxes = np.empty((cap, 4), np.int32)
+    n = check(lib.mf_contour_boxes(image.ctypes.data, h, w, int(reverse_order), boxes.ctypes.data, cap))
+    return boxes[:min(n, cap)]
 
 
 class SemanticProjectionLayer(BaseProjectionLayer):
@@ -73,6 +89,85 @@ class SemanticProjectionLayer(BaseProjectionLayer):
                     observation["depth"], self._labels(observation["semantic"], validate),
                     sequential=sequential)
         return self
+
+    # ------------------------------------------------------------------ find
+    def _voxel_centres(self):
+        """World coordinate of the voxel centre per index (what map_to_world returns for
+        integer coordinates, base_projection_layer.py:479-511); y is stored flipped."""
+        cx = (self.bins_x[:-1] + self.bins_x[1:]) / 2
+        cy = ((self.bins_y[:-1] + self.bins_y[1:]) / 2).flip(-1)
+        cz = (self.bins_z[:-1] + self.bins_z[1:]) / 2
+        return cx.contiguous(), cy.contiguous(), cz.contiguous()
+
+    def class_images(self, contour_threshold: float = 0.0):
+        """[H, W, C] bool: (data > threshold).any(dim=2) for every class in ONE pass over the
+        map (the reference re-reads the whole map once per class).  Cached until the map
+        changes through update()/reset()."""
+        key = (self._map_version, float(contour_threshold))
+        if getattr(self, "_class_images", None) is None or self._class_images[0] != key:
+            self._class_images = (key, amax_z(self.data) > contour_threshold)
+        return self._class_images[1]
+
+    def find(self, semantic_category: int, confidence_threshold: float = 0.2,
+             contour_padding: int = 3, contour_threshold: float = 0.0,
+             feature_map=None):
+        """Instances of one class: per connected blob of the top-down class image, the expected
+        world position, confidence, size in voxels and (optionally) the expected feature vector
+        (semantic_projection_layer.py:257-362).  Returns (confidences, coordinates, sizes,
+        features or None) as lists of tensors, one entry per detection."""
+        data = self.data
+        c = int(semantic_category)
+        if contour_padding == 0:
+            image = self.class_images(contour_threshold)[..., c]
+        else:
+            # smoothing with a (2p+1)^3 box filter first (avg_pool3d, zero padded): plain torch
+            smooth = functional.avg_pool3d(data[..., c][None, None], contour_padding * 2 + 1, stride=1,
+                                           padding=contour_padding)[0, 0]
+            image = (smooth > contour_threshold).any(dim=2)
+        boxes = contour_boxes(image.to(torch.uint8).cpu().numpy())
+
+        self.boxes, coordinates, confidences, sizes, features = [], [], [], [], []
+        want_feat = feature_map is not None
+        if len(boxes) == 0:
+            return confidences, coordinates, sizes, features if want_feat else None
+
+        cx, cy, cz = self._voxel_centres()
+        dev = data.device
+        boxes_d = torch.as_tensor(boxes, device=dev)
+        n = len(boxes)
+        moments = torch.empty(n, 5, dtype=torch.float32, device=dev)
+        fdata = feat_out = None
+        on_device = want_feat and feature_map.data.device == dev
+        if on_device:
+            fdata = feature_map.data
+            if fdata.dtype != torch.float32 or not fdata.is_contiguous() or fdata.shape[:3] != data.shape[:3]:
+                raise ValueError("feature_map.data must be a contiguous float32 map of the same grid")
+            feat_out = torch.empty(n, fdata.shape[-1], dtype=torch.float32, device=dev)
+        check(lib.mf_roi_moments(ptr(data), data.shape[0], data.shape[1], data.shape[2], data.shape[3], c,
+                                 ptr(cx), ptr(cy), ptr(cz), ptr(boxes_d), n, ptr(fdata),
+                                 fdata.shape[-1] if on_device else 0, ptr(moments), ptr(feat_out),
+                                 current_stream(dev)))
+        s1, s2 = moments[:, 0], moments[:, 1]
+        den = s1 + 1e-9                                   # weights = mask_roi / (mask_roi.sum() + 1e-9)
+        conf = s2 / den
+        centre = moments[:, 2:5] / den[:, None]
+        keep = (conf > confidence_threshold).cpu().numpy()
+        for k in range(n):
+            if not keep[k]:
+                continue
+            x, y, w, h = (int(v) for v in boxes[k])
+            self.boxes.append((x, y, w, h))
+            confidences.append(conf[k])
+            coordinates.append(centre[k])
+            sizes.append(s1[k])
+            if want_feat:
+                if on_device:
+                    features.append(feat_out[k] / den[k])
+                else:                                     # e.g. a feature map kept on the CPU (agent.py:711-742)
+                    roi = feature_map.data[y:y + h, x:x + w].to(dev)
+                    wts = data[y:y + h, x:x + w, :, c:c + 1] / den[k]
+                    features.append((roi * wts).sum(dim=(0, 1, 2)))
+        return confidences, coordinates, sizes, features if want_feat else None
 
     def visualize(self, obs: Dict[str, Any], depth_slice: slice = slice(0, 32)):
         """Top-down class colour image (semantic_projection_layer.py:218-255,

@@ -58,11 +58,13 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         self.register_buffer('bins_y', _edges(origin_y, map_height, grid_resolution))
         self.register_buffer('bins_z', _edges(origin_z, map_depth, grid_resolution))
         self._workspace = Workspace()
+        self._map_version = 0          # bumped whenever update()/reset() change the map
 
     # ------------------------------------------------------------------ state
     def reset(self, origin_y: float = 0.0, origin_x: float = 0.0, origin_z: float = 0.0):
         """Zero the map and re-centre the bin edges (base_projection_layer.py:183-235)."""
         self.origin_x, self.origin_y, self.origin_z = origin_x, origin_y, origin_z
+        self._map_version += 1
         self.data.zero_()
         self.bins_x.copy_(_edges(origin_x, self.map_width, self.grid_resolution))
         self.bins_y.copy_(_edges(origin_y, self.map_height, self.grid_resolution))
@@ -90,6 +92,7 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
 
     def _splat(self, position, yaw, elevation, depth, features, sequential=True):
         depth = torch.as_tensor(depth, dtype=torch.float32, device=self.data.device)
+        self._map_version += 1
         fuse_frames(self.bins_x, self.bins_y, self.bins_z, self.rays,
                     self._poses(position, yaw, elevation), depth, features, self.data,
                     interpolation_weight=self.interpolation_weight, sequential=sequential,

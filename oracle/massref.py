@@ -253,3 +253,58 @@ def match(f0, f1):
     cost = pairwise_l2(f0, f1).numpy()
     rows, cols = linear_sum_assignment(cost)
     return cost, rows, cols
+
+
+# --------------------------------------------------------------------------
+# SemanticProjectionLayer.find (mass/nn/applications/semantic_projection_layer.py:257-362)
+# --------------------------------------------------------------------------
+
+def border_boxes(image):
+    """Bounding boxes (x, y, w, h) of the borders cv2.findContours(RETR_LIST) would report:
+    one per 8-connected component, one per enclosed 4-connected background region (its box
+    grown by one pixel).  cv2 is absent here, so the ORDER is canonical (sorted), not cv2's:
+    parity unpinned for the order of detections."""
+    from scipy import ndimage
+    img = np.asarray(image) != 0
+    out = []
+    lab, _ = ndimage.label(img, structure=np.ones((3, 3)))
+    for sl in ndimage.find_objects(lab):
+        out.append((sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start))
+    bg, _ = ndimage.label(~np.pad(img, 1), structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    for k, sl in enumerate(ndimage.find_objects(bg), start=1):
+        if k == bg[0, 0]:
+            continue
+        out.append((sl[1].start - 2, sl[0].start - 2, sl[1].stop - sl[1].start + 2, sl[0].stop - sl[0].start + 2))
+    return sorted(out)
+
+
+def find(data, bins_x, bins_y, bins_z, semantic_category, confidence_threshold=0.2, contour_padding=3,
+         contour_threshold=0.0, feature_data=None):
+    """The reference's find() on CPU tensors, op for op (:298-357), with border_boxes()
+    standing in for cv2.  Returns a list of dicts sorted by box."""
+    import torch.nn.functional as functional
+    data = torch.as_tensor(data)
+    H, W, D, _ = data.shape
+    c = semantic_category
+    cx = (bins_x[:-1] + bins_x[1:]) / 2
+    cy = ((bins_y[:-1] + bins_y[1:]) / 2).flip(-1)
+    cz = (bins_z[:-1] + bins_z[1:]) / 2
+    yy, xx, zz = torch.meshgrid(torch.arange(H), torch.arange(W), torch.arange(D), indexing='ij')
+    coords = torch.stack([cx[xx], cy[yy], cz[zz]], dim=-1)            # map_to_world of integer coordinates
+    mask = data[..., c:c + 1]
+    smooth = mask.permute(3, 0, 1, 2).unsqueeze(0)
+    smooth = functional.avg_pool3d(smooth, contour_padding * 2 + 1, stride=1, padding=contour_padding)
+    smooth = smooth.squeeze(0).permute(1, 2, 3, 0)
+    image = (smooth > contour_threshold).any(dim=2).numpy().astype(np.uint8)[:, :, 0]
+    out = []
+    for x, y, w, h in border_boxes(image):
+        mask_roi = mask[y:y + h, x:x + w]
+        weights = mask_roi / (mask_roi.sum() + 1e-9)
+        conf = (mask_roi * weights).sum()
+        if conf > confidence_threshold:
+            d = dict(box=(x, y, w, h), confidence=float(conf), size=float(mask_roi.sum()),
+                     coordinate=(coords[y:y + h, x:x + w] * weights).sum(dim=(0, 1, 2)).numpy())
+            if feature_data is not None:
+                d["feature"] = (torch.as_tensor(feature_data)[y:y + h, x:x + w] * weights).sum(dim=(0, 1, 2)).numpy()
+            out.append(d)
+    return out
