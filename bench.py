@@ -32,8 +32,8 @@ H, W, C, MAP, BATCH = 480, 640, 54, 256, 64
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--workload", default="distA", choices=["distA", "room"])
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the batch timed through the CPU oracle")

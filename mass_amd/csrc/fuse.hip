@@ -417,6 +417,16 @@ __device__ __forceinline__ void lds_add_f32(float *p, float x)
 #endif
 }
 
+// Workgroup barrier that leaves vector-memory operations (the LDS-DMA preload, prefetched
+// records) in flight: __syncthreads() drains vmcnt when an LDS-DMA is outstanding.  LDS
+// traffic of this wave is retired first; the compiler may not move memory ops across it.
+__device__ __forceinline__ void barrier_keep_vm()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float klow(const unsigned long long *W64, int i)
 {
     return reinterpret_cast<const float *>(W64 + i)[0];
@@ -553,9 +563,33 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             }
             if (tid == 0) misc[1] = count;
         }
-        for (unsigned i = tid; i < n_el; i += NT) D[i] = 0.0f;
+        if (P.vec4) {
+            // Preload the tile's current map values straight into D with LDS-DMA (no VGPRs):
+            // with D_0 = m_0 and s = 1 the invariant "true value = s * D" covers the old map
+            // too, the final pass becomes write-only, and the 110 KB read overlaps pass 1.
+            // One wave instruction moves 64 x 16 B = 1 KB; the LDS side is linear, the global
+            // side is per lane (tile rows of T2*C floats are contiguous in the map).
+            const unsigned n4 = n_el >> 2, row_len = (unsigned)C << P.s2;
+            for (unsigned q0 = (unsigned)(tid & ~63); q0 < n4; q0 += NT) {
+                const unsigned q = q0 + (tid & 63);
+                if (q < n4) {
+                    const unsigned i = q << 2;
+                    const unsigned r = div_magic(i, P.magicC) >> P.s2;     // row = (l0, l1)
+                    const int l1 = r & m1, l0 = r >> P.s1;
+                    if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
+                        const float *g = P.map + ((((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C +
+                                                  (i - r * row_len));
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)g,
+                            (__attribute__((address_space(3))) void *)(D + ((size_t)q0 << 2)), 16, 0, 0);
+                    }
+                }
+            }
+        } else {
+            for (unsigned i = tid; i < n_el; i += NT) D[i] = 0.0f;
+        }
         for (int v = tid; v < TV; v += NT) { sc[v] = 1.0f; osc[v] = 1.0f; touched[v] = 0; }
-        __syncthreads();
+        barrier_keep_vm();
         MF_STAMP(1)
         const int n_ne = misc[1];
 
@@ -563,7 +597,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             const int nc = min(GC, n_ne - c0);
             for (int i = tid; i < nc * TV; i += NT) { W64[i] = 0ull; S64[i] = 0ull; }
             if (tid <= nc) cb[tid] = tid < nc ? offs[ne[c0 + tid]] : offs[ne[c0 + nc - 1] + 1];
-            __syncthreads();
+            barrier_keep_vm();
             MF_STAMP(2)
             const int ea = cb[0], eb = cb[nc];
             // slot of entry e inside the chunk = number of frame starts cb[1..nc-1] that are <= e
@@ -604,7 +638,8 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                     }
             }
             if (c0 == 0 && tid == 0) misc[2] = resolve(idx_next);
-            __syncthreads();
+            if (c0 == 0 && P.vec4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces
+            barrier_keep_vm();
             MF_STAMP(3)
             // pass 2: per voxel, frames in order: s *= a_f, k_f = g_f / s
             for (int v = tid; v < TV; v += NT) {
@@ -689,47 +724,24 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
         // float4 that straddles a touched and an untouched voxel rewrites the latter unchanged
         // (s = prod a = 1, D = 0), which is safe because the whole box belongs to this tile.
         if (P.vec4) {
+            // D already contains the old values (preloaded above): true = s * D, store only
             const unsigned row_len = (unsigned)C << P.s2;          // floats per tile row
             const unsigned n4 = n_el >> 2;
-            const float4 *map4 = reinterpret_cast<const float4 *>(P.map);
             float4 *map4w = reinterpret_cast<float4 *>(P.map);
-            constexpr int U = MF_FU;
-            for (unsigned b = 0; b < n4; b += NT * U) {
-                float4 old[U];
-                unsigned gq[U], li[U];
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    const unsigned q = b + j * NT + tid;
-                    li[j] = 0xffffffffu;
-                    if (q < n4) {
-                        const unsigned i = q << 2;
-                        const unsigned va = div_magic(i, P.magicC), vb = div_magic(i + 3, P.magicC);
-                        bool t = touched[va] | touched[vb];
-                        if (C < 3) t = t | touched[div_magic(i + 1, P.magicC)] | touched[div_magic(i + 2, P.magicC)];
-                        if (t) {
-                            const unsigned r = va >> P.s2;                 // row = (l0, l1)
-                            const int l1 = r & m1, l0 = r >> P.s1;
-                            const size_t g = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len);
-                            gq[j] = (unsigned)(g >> 2);
-                            li[j] = i;
-                            old[j] = map4[gq[j]];
-                        }
-                    }
+            for (unsigned q = tid; q < n4; q += NT) {
+                const unsigned i = q << 2;
+                const unsigned v0 = div_magic(i, P.magicC), v3 = div_magic(i + 3, P.magicC);
+                const unsigned v1 = C < 3 ? div_magic(i + 1, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 1, P.magicC));
+                const unsigned v2 = C < 3 ? div_magic(i + 2, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 2, P.magicC));
+                if (touched[v0] | touched[v1] | touched[v2] | touched[v3]) {
+                    const unsigned r = v0 >> P.s2;                 // row = (l0, l1)
+                    const int l1 = r & m1, l0 = r >> P.s1;
+                    const size_t g = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len);
+                    const float4 d = *reinterpret_cast<const float4 *>(D + i);
+                    float4 o;
+                    o.x = sc[v0] * d.x; o.y = sc[v1] * d.y; o.z = sc[v2] * d.z; o.w = sc[v3] * d.w;
+                    map4w[g >> 2] = o;
                 }
-#pragma unroll
-                for (int j = 0; j < U; ++j)
-                    if (li[j] != 0xffffffffu) {
-                        const unsigned i = li[j];
-                        const float4 d = *reinterpret_cast<const float4 *>(D + i);
-                        const unsigned v0 = div_magic(i, P.magicC), v1 = div_magic(i + 1, P.magicC),
-                                       v2 = div_magic(i + 2, P.magicC), v3 = div_magic(i + 3, P.magicC);
-                        float4 o;
-                        o.x = osc[v0] * old[j].x + sc[v0] * d.x;
-                        o.y = osc[v1] * old[j].y + sc[v1] * d.y;
-                        o.z = osc[v2] * old[j].z + sc[v2] * d.z;
-                        o.w = osc[v3] * old[j].w + sc[v3] * d.w;
-                        map4w[gq[j]] = o;
-                    }
             }
         } else {
             constexpr int U = 4;
