@@ -365,17 +365,26 @@ __device__ __forceinline__ void for_corners(const TileParams &P, const uint4 &r,
     const AxisFoot a0 = axis_foot(k0, __uint_as_float(r.y), P.size0);
     const AxisFoot a1 = axis_foot(k1, __uint_as_float(r.z), P.size1);
     const AxisFoot a2 = axis_foot(k2, __uint_as_float(r.w), P.size2);
-    // tile-local coordinates of the lower corner and whether the upper one is a different voxel
-    const unsigned l0 = (unsigned)(a0.lo - o0), l1 = (unsigned)(a1.lo - o1), l2 = (unsigned)(a2.lo - o2);
-    const unsigned d0 = (unsigned)(a0.hi - a0.lo), d1 = (unsigned)(a1.hi - a1.lo), d2 = (unsigned)(a2.hi - a2.lo);
-    // rolled on purpose: the body is expanded once, which keeps the kernel inside 128 VGPRs
-#pragma nounroll
+    // per axis: tile-local coordinate of the lower / upper corner, pre-shifted into its field of
+    // the local voxel id, and whether it lies inside the tile
+    const unsigned l0 = (unsigned)(a0.lo - o0), h0 = (unsigned)(a0.hi - o0);
+    const unsigned l1 = (unsigned)(a1.lo - o1), h1 = (unsigned)(a1.hi - o1);
+    const unsigned l2 = (unsigned)(a2.lo - o2), h2 = (unsigned)(a2.hi - o2);
+    const bool in0[2] = {(l0 >> P.s0) == 0, (h0 >> P.s0) == 0};
+    const bool in1[2] = {(l1 >> P.s1) == 0, (h1 >> P.s1) == 0};
+    const bool in2[2] = {(l2 >> P.s2) == 0, (h2 >> P.s2) == 0};
+    const unsigned p0[2] = {l0 << (P.s1 + P.s2), h0 << (P.s1 + P.s2)};
+    const unsigned p1[2] = {l1 << P.s2, h1 << P.s2};
+    const unsigned p2[2] = {l2, h2};
+    // (w0 * w1) first, like the reference's product order (projection.py:319-323)
+    const float w01[4] = {a0.wlo * a1.wlo, a0.wlo * a1.whi, a0.whi * a1.wlo, a0.whi * a1.whi};
+    const float w2[2] = {a2.wlo, a2.whi};
+#pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-        const bool ha = cc & 4, hb = cc & 2, hd = cc & 1;
-        const unsigned c0 = l0 + (ha ? d0 : 0u), c1 = l1 + (hb ? d1 : 0u), c2 = l2 + (hd ? d2 : 0u);
-        if ((c0 >> P.s0) == 0 && (c1 >> P.s1) == 0 && (c2 >> P.s2) == 0) {
-            const int v = (int)((((c0 << P.s1) | c1) << P.s2) | c2);
-            body(v, corner_weight(ha ? a0.whi : a0.wlo, hb ? a1.whi : a1.wlo, hd ? a2.whi : a2.wlo));
+        const int ca = cc >> 2, cb = (cc >> 1) & 1, cd = cc & 1;
+        if (in0[ca] && in1[cb] && in2[cd]) {
+            const float pw = w01[ca * 2 + cb] * w2[cd];
+            body((int)(p0[ca] | p1[cb] | p2[cd]), 1e-9f + pw);
         }
     }
 }
