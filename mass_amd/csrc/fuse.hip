@@ -868,7 +868,7 @@ static bool tile_override(int &s0, int &s1, int &s2, int &nt)
     return have;
 }
 
-static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
+static void choose_tile(const mf_grid *g, int n_groups, int &s0, int &s1, int &s2)
 {
     int nt_unused;
     if (tile_override(s0, s1, s2, nt_unused)) return;
@@ -877,6 +877,10 @@ static void choose_tile(const mf_grid *g, int &s0, int &s1, int &s2)
     unsigned tv = (unsigned)(budget / per_voxel);
     if (tv < 1) tv = 1;
     if (tv > 512) tv = 512;       // larger tiles starve the chip when a scene concentrates on few tiles
+    // a single frame of a real scene lands on few tiles (a wall near the camera); 4 x 4 x 8
+    // tiles give four times the workgroups for the same points, and with one or two frames
+    // there is little temporal reuse of a tile's LDS image to lose
+    if (n_groups <= 2 && tv > 128) tv = 128;
     int sv = ilog2_floor(tv);
     s2 = 3;
     if (s2 > sv) s2 = sv;
@@ -1016,7 +1020,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (P.G < 1 || P.G > MAX_GROUPS)
         return fail(MF_ERR_INVALID, "at most %d sequential frames per call, got %d", MAX_GROUPS, P.G);
     if (P.n_points == 0) return MF_OK;
-    choose_tile(grid, P.s0, P.s1, P.s2);
+    choose_tile(grid, P.G, P.s0, P.s1, P.s2);
     Layout L;
     if (!make_layout(grid, P.n_points, P.G, P.s0, P.s1, P.s2, L, P.nt0, P.nt1, P.nt2))
         return fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets (points %lld, groups %d)",
@@ -1149,7 +1153,7 @@ size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int32_t n_
         return 0;
     }
     int s0, s1, s2, a, b, c;
-    choose_tile(grid, s0, s1, s2);
+    choose_tile(grid, n_groups, s0, s1, s2);
     Layout L;
     if (!make_layout(grid, n_points, n_groups, s0, s1, s2, L, a, b, c)) {
         fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets");
