@@ -32,8 +32,8 @@ H, W, C, MAP, BATCH = 480, 640, 54, 256, 64
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--workload", default="distA", choices=["distA", "room"])
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the batch timed through the CPU oracle")
@@ -98,7 +98,15 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env == 1 and args.gpus > 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    rank, world, local_rank = D.init_from_env(backend="nccl")      # nccl == RCCL on ROCm
+    # nccl == RCCL on ROCm.  MF_BENCH_BACKEND=gloo is a rehearsal knob for boxes with fewer GPUs
+    # than ranks (ranks then share device rank % device_count); the driver never sets it.
+    backend = os.environ.get("MF_BENCH_BACKEND", "nccl")
+    n_dev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl":
+        rank, world, local_rank = D.init_from_env(backend="nccl")
+    else:
+        rank, world, local_rank = D.init_from_env(backend=backend)
+        local_rank %= n_dev
     args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -128,7 +136,8 @@ def main():
         step()
     barrier()
     _lib.check(_lib.lib.mf_profile_enable(1))
-    stage_ms = np.zeros((args.steps, 5), np.float32)
+    n_prof = min(args.steps, 256)            # the library keeps events for 256 calls
+    stage_ms = np.zeros((n_prof, 5), np.float32)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -137,7 +146,7 @@ def main():
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
-    for k in range(args.steps):
+    for k in range(n_prof):
         _lib.check(_lib.lib.mf_profile_read(k, stage_ms[k].ctypes.data))
     _lib.check(_lib.lib.mf_profile_enable(0))
     gpu_ms = ev0.elapsed_time(ev1)

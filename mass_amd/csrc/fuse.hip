@@ -182,7 +182,7 @@ __device__ __forceinline__ int point_keys(const FuseParams &P, const Point &pt, 
 // per-block LDS hash: bucket key -> (count, base)
 // ----------------------------------------------------------------------------
 constexpr int BIN_THREADS = 256;
-constexpr int HS_BITS = 11;
+constexpr int HS_BITS = 8;
 constexpr int HS = 1 << HS_BITS;
 constexpr uint32_t EMPTY = 0xffffffffu;
 
