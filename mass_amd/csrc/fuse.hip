@@ -405,6 +405,18 @@ __device__ unsigned long long g_stamps[8];
 #ifndef MF_FU
 #define MF_FU 4
 #endif
+// w * 2^shift as a 64-bit integer (truncated), for 0 <= w < 2^(40 - shift + ...): built from the
+// float's bits with one 64-bit shift instead of the seven-instruction float -> u64 conversion.
+// fx_c = 182 - shift; a result below one unit (or w == 0) comes out as 0.
+__device__ __forceinline__ unsigned long long to_fixed(float w, int fx_c)
+{
+    const unsigned b = __float_as_uint(w);
+    const unsigned m = (b & 0x7fffffu) | 0x800000u;             // 24-bit significand
+    int amt = fx_c - (int)(b >> 23);                            // (m << 32) >> amt == m * 2^(e - 150 + shift)
+    amt = amt > 63 ? 63 : amt;                                  // m << 32 < 2^56, so 63 yields 0
+    return ((unsigned long long)m << 32) >> amt;
+}
+
 // LDS float add.  ds_add_f32 costs ~80 ns per wave instruction on gfx950 whatever the
 // address pattern; one compare-and-swap round trip on the bit pattern costs ~11 ns when the
 // lanes of a wave hit distinct words.  Try the swap once, and let only the lanes that lost a
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     const int G = P.G;
     const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
     const unsigned n_el = (unsigned)TV * (unsigned)C;
-    const float fx_scale = __uint_as_float((unsigned)(127 + P.fx_shift) << 23);    // 2^shift
+    const int fx_c = 182 - P.fx_shift;
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);      // 2^-shift
 
     // The work list is walked with a ticket counter.  Everything the NEXT tile needs before
@@ -638,10 +650,10 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 #if defined(MF_ABL_NOATOM)
                             asm volatile("" ::"v"(v), "v"(w), "v"(base));      // ablation: no LDS atomics
 #elif defined(MF_ABL_PLAINST)
-                            W64[base + v] = (unsigned long long)(w * fx_scale); S64[base + v] = 1;   // ablation: plain LDS stores
+                            W64[base + v] = to_fixed(w, fx_c); S64[base + v] = 1;   // ablation: plain LDS stores
 #else
-                            atomicAdd(&W64[base + v], (unsigned long long)(w * fx_scale));
-                            atomicAdd(&S64[base + v], (unsigned long long)((w * w) * fx_scale));
+                            atomicAdd(&W64[base + v], to_fixed(w, fx_c));
+                            atomicAdd(&S64[base + v], to_fixed(w * w, fx_c));
 #endif
                         });
                     }
