@@ -6,26 +6,33 @@
 //   update_feature_map  projection.py:233-351
 // as driven by BaseProjectionLayer.update (mass/nn/base_projection_layer.py:282-343).
 //
-// Design (see DESIGN.md): the reference's read-modify-write blend
+// Design (DESIGN.md section 4): the reference's read-modify-write blend
 //     new[v] = sum_k ((1 - iw*w_k)*old[v] + iw*w_k*f_k) * w_k / W[v]
-// is evaluated in its closed form
-//     new[v] = old[v] * (1 - iw*S2/W) + (iw/W) * sum_k w_k^2 f_k ,  W = sum w_k, S2 = sum w_k^2
-// by one workgroup per *map tile* that keeps the tile's voxels in LDS:
-//   1. count   : every pixel is unprojected and binned (bit-exact integer
-//                path), its 2x2x2 footprint is mapped to the <=8 tiles it
-//                overlaps, and (tile, group) bucket sizes are counted with a
-//                per-block LDS hash so one global atomic is issued per
-//                distinct bucket per block;
-//   2. scan    : exclusive prefix sum of the bucket sizes;
-//   3. scatter : the same pass again, now writing a 20-byte point record into
-//                its bucket slot (slot = bucket base + LDS-local rank);
-//   4. fuse    : persistent workgroups pull tiles from a ticket counter, load
-//                the touched voxels of the tile into LDS, and for each group
-//                (= frame, in order) accumulate W and S2 with LDS float
-//                atomics, decay the touched voxels, add the w^2-weighted
-//                features, and finally write the touched voxels back.
-// No global float atomics are used (they run at ~1.3 TB/s and 17x slower when
-// scattered); HBM sees each touched voxel once per call, coalesced along z.
+// has the closed form
+//     new[v] = a*old[v] + g*U ,  a = 1 - iw*S2/W, g = iw/W, W = sum w_k, S2 = sum w_k^2, U = sum w_k^2 f_k
+// and a sequence of frames unrolls to  m_n = s_n * (m_0 + sum_f (g_f / s_f) U_f),  s_f = prod a.
+// One workgroup per *map tile* keeps the tile in LDS across all frames of the call:
+//   1. count     : every pixel is unprojected and binned (bit-exact integer path), its 2x2x2
+//                  footprint is mapped to the <= 8 tiles it overlaps, and (tile, frame) bucket
+//                  sizes are counted through a per-block LDS hash, so a block issues one global
+//                  integer atomic per distinct bucket (blocks own 16 x 16 pixel patches);
+//   2. scan      : exclusive prefix sum of the bucket sizes; list of non-empty tiles, heaviest
+//                  load class first;
+//   3. scatter   : the same geometry again, now writing a 20-byte point record into its
+//                  bucket slot (slot = bucket base + LDS-local rank);
+//   4. fuse_tiles: persistent workgroups walk the tile list (ticket counter; the next tile's
+//                  ticket, id, offsets and first records are fetched one tile ahead).  The
+//                  tile's old map values are preloaded into LDS by LDS-DMA while pass 1 runs;
+//                  frames are taken in chunks: pass 1 accumulates W, S2 as 64-bit fixed-point
+//                  LDS integer atomics (ds_add_f32 is 29x slower than ds_add_u32 on gfx950),
+//                  pass 2 turns them into k_f = g_f / s_f per voxel, pass 3 adds w^2 k_f feat
+//                  (one compare-and-swap, float atomic only on a lost race); the final pass
+//                  writes s * D for every touched voxel, as float4, exactly once per call.
+// No global float atomics are used (guide: ~1.3 TB/s, 17x slower when scattered); HBM sees each
+// touched voxel once per call, coalesced along z.
+//
+// Tuning / diagnostics, all off by default: MF_TILE="s0 s1 s2 threads [gc]" overrides the tile
+// shape, MF_STAMPS=1 prints the share of each phase of the tile kernel (dev builds of bench runs).
 #include <cstdlib>
 #include "common.h"
 #include "geometry.h"
@@ -211,12 +218,8 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
             uint32_t keys[8];
             const int n = point_keys(P, pt, keys);
             for (int i = 0; i < n; ++i) {
-#ifdef MF_ABL_COUNT_NOHASH
-                asm volatile("" ::"v"(keys[i]));
-#else
                 int rank;
                 if (hash_insert(hkey, hcnt, keys[i], rank) < 0) atomicAdd(&P.cursor[keys[i]], 1);
-#endif
             }
         }
     }
@@ -319,11 +322,7 @@ constexpr int TILE_CLASSES = 4;
 
 __device__ __forceinline__ int tile_class(int n)
 {
-#ifdef MF_ONE_CLASS
-    return 0;
-#else
     return n >= 8192 ? 0 : n >= 2048 ? 1 : n >= 512 ? 2 : 3;
-#endif
 }
 
 __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
@@ -399,12 +398,6 @@ __device__ unsigned long long g_stamps[8];
         t_last = _t;                                                                  \
     }
 
-#ifndef MF_EB
-#define MF_EB 2
-#endif
-#ifndef MF_FU
-#define MF_FU 4
-#endif
 // w * 2^shift as a 64-bit integer (truncated), for 0 <= w < 2^(40 - shift + ...): built from the
 // float's bits with one 64-bit shift instead of the seven-instruction float -> u64 conversion.
 // fx_c = 182 - shift; a result below one unit (or w == 0) comes out as 0.
@@ -424,18 +417,9 @@ __device__ __forceinline__ unsigned long long to_fixed(float w, int fx_c)
 __device__ __forceinline__ void lds_add_f32(float *p, float x)
 {
     unsigned *u = reinterpret_cast<unsigned *>(p);
-#ifdef MF_CAS_LOOP
-    unsigned seen = *u, prev;
-    for (;;) {
-        prev = atomicCAS(u, seen, __float_as_uint(__uint_as_float(seen) + x));
-        if (prev == seen) break;
-        seen = prev;
-    }
-#else
     const unsigned seen = *u;
     const unsigned prev = atomicCAS(u, seen, __float_as_uint(__uint_as_float(seen) + x));
     if (prev != seen) atomicAdd(p, x);
-#endif
 }
 
 // Workgroup barrier that leaves vector-memory operations (the LDS-DMA preload, prefetched
@@ -453,7 +437,7 @@ __device__ __forceinline__ float klow(const unsigned long long *W64, int i)
     return reinterpret_cast<const float *>(W64 + i)[0];
 }
 
-constexpr int EB = MF_EB;                  // entries a thread keeps in flight / in registers per batch
+constexpr int EB = 2;                       // entries a thread keeps in flight / in registers per batch
 constexpr int MAX_CHUNK = 16;          // frames whose W / S2 accumulators are live at once
 constexpr float RESCALE_BELOW = 9.094947e-13f;   // 2^-40: fold the lazy decay into the deltas below this
 
@@ -647,14 +631,8 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                     if (r[j].x != 0xffffffffu) {
                         const int base = slot_of(bb + tid + j * NT) * TV;
                         for_corners(P, r[j], o0, o1, o2, [&](int v, float w) {
-#if defined(MF_ABL_NOATOM)
-                            asm volatile("" ::"v"(v), "v"(w), "v"(base));      // ablation: no LDS atomics
-#elif defined(MF_ABL_PLAINST)
-                            W64[base + v] = to_fixed(w, fx_c); S64[base + v] = 1;   // ablation: plain LDS stores
-#else
                             atomicAdd(&W64[base + v], to_fixed(w, fx_c));
                             atomicAdd(&S64[base + v], to_fixed(w * w, fx_c));
-#endif
                         });
                     }
             }
@@ -1075,7 +1053,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     const int sv = P.s0 + P.s1 + P.s2;
     P.gc = chunk_frames(P.C, sv, P.G);
     P.vec4 = ((uintptr_t)P.map % 16 == 0) && ((P.C << P.s2) % 4 == 0) && (P.size2 % (1 << P.s2) == 0) &&
-             ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34)) && getenv("MF_NO_VEC4") == nullptr;
+             ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34));
     const size_t lds = tile_lds_bytes(P.C, sv, P.gc);
     const DeviceInfo &dev = device_info();
     if (lds > (size_t)dev.lds_per_cu)
