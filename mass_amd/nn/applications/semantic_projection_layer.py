@@ -61,6 +61,9 @@ class SemanticProjectionLayer(BaseProjectionLayer):
             origin_y=origin_y, origin_x=origin_x, origin_z=origin_z)
 
     def _labels(self, semantic, validate):
+        """Class-id image for the kernel: [H, W] (or [B, H, W]) uint8 / int32 / int64 on the
+        device.  Host arrays are uploaded as they are (an int64 480x640 image is 2.4 MB and takes
+        ~60 us; narrowing it on the host first costs far more than it saves)."""
         semantic = torch.as_tensor(semantic)
         if semantic.is_floating_point():
             semantic = semantic.to(torch.int64)
