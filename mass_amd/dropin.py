@@ -18,6 +18,7 @@ _MODULES = {
     "nn.base_projection_layer": "mass_amd.nn.base_projection_layer",
     "nn.applications.occupancy_projection_layer": "mass_amd.nn.applications.occupancy_projection_layer",
     "nn.applications.semantic_projection_layer": "mass_amd.nn.applications.semantic_projection_layer",
+    "nn.applications.resnet_projection_layer": "mass_amd.nn.applications.resnet_projection_layer",
 }
 
 

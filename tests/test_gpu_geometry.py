@@ -114,3 +114,37 @@ def test_nonuniform_and_tiny_bins(device):
     assert np.array_equal(out[0][0].cpu().numpy(), want.numpy())
     ok = (want >= 0) & (want < edges.numel() - 1)
     assert np.array_equal(out[6][0].cpu().numpy().astype(bool), ok.numpy())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations_bit_exact_vs_oracle(device, seed):
+    """Random cameras, map sizes, resolutions, origins and poses: the fused unproject+bin of the
+    hot path must equal the oracle (itself bit-identical to the reference) in every index, ratio
+    and validity bit."""
+    from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+    from mass_amd.utils.projection import unproject_bin
+    from oracle import massref as orc
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = lambda lo, hi: float(lo + (hi - lo) * torch.rand((), generator=g))
+    h, w = int(torch.randint(8, 97, (1,), generator=g)), int(torch.randint(8, 129, (1,), generator=g))
+    kw = dict(camera_height=h, camera_width=w, vertical_fov=r(50, 110), map_height=int(torch.randint(5, 70, (1,), generator=g)),
+              map_width=int(torch.randint(5, 70, (1,), generator=g)), map_depth=int(torch.randint(3, 40, (1,), generator=g)),
+              feature_size=1, grid_resolution=r(0.02, 0.3), origin_y=r(-5, 5), origin_x=r(-5, 5), origin_z=r(-1, 1))
+    lay = BaseProjectionLayer(**kw).to(device)
+    ol = orc.RefProjectionLayer(**kw)
+    assert np.array_equal(lay.rays.cpu().numpy(), ol.rays.numpy())
+    n = 3
+    pos = torch.tensor([kw["origin_x"], kw["origin_y"], kw["origin_z"]]) + 0.5 * torch.randn(n, 3, generator=g)
+    yaw, el = 6.3 * torch.rand(n, generator=g), 1.5 * torch.rand(n, generator=g) - 1.0
+    span = kw["grid_resolution"] * max(kw["map_height"], kw["map_width"])
+    depth = span * torch.rand(n, h, w, 1, generator=g) ** 2
+    out = unproject_bin(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, lay._poses(pos, yaw, el), depth.to(device))
+    for b in range(n):
+        world = orc.transform_rays(ol.rays, orc.spherical_to_cartesian(yaw[b], el[b]),
+                                   orc.spherical_to_cartesian(yaw[b], el[b] + np.pi / 2))
+        o = orc.bin_rays_dense(ol.bins_x, ol.bins_y, ol.bins_z, pos[b], world, depth[b])
+        valid = o["valid"].astype(bool)
+        assert np.array_equal(out[6][b].cpu().numpy().astype(bool), valid)
+        for k, a in zip(("ind0", "ind1", "ind2", "ratio0", "ratio1", "ratio2"), out[:6]):
+            assert np.array_equal(a[b].cpu().numpy()[valid], o[k][valid]), (seed, b, k)
+    assert valid.any()

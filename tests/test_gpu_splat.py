@@ -186,3 +186,30 @@ def test_long_sequential_batch_vs_oracle_loop(device, iw, kind, C):
     for t in range(n):
         ol.update(dict(position=pos[t], yaw=yaw[t], elevation=el[t], depth=depth[t], features=feats[t]))
     assert_map_close(lay.data.cpu().numpy(), ol.data.numpy())
+
+
+def test_resnet_layer_splat_at_quarter_resolution(device):
+    """ResNetProjectionLayer: features at camera/4 with the depth sampled at feature-pixel centres
+    (resnet_projection_layer.py:201-211); the CNN is replaced by a stand-in extractor."""
+    from mass_amd.nn.applications.resnet_projection_layer import ResNetProjectionLayer
+    from oracle import massref as orc
+    Hc, Wc, C = 48, 64, 16
+    g = torch.Generator().manual_seed(21)
+    proj = torch.rand(3, C, generator=g)
+
+    def extractor(rgb):                                   # [H, W, 3] -> [H/4, W/4, C]
+        x = torch.as_tensor(rgb, dtype=torch.float32)
+        x = x.reshape(Hc // 4, 4, Wc // 4, 4, 3).mean(dim=(1, 3))
+        return torch.relu(x @ proj)
+
+    kw = dict(map_height=MAP, map_width=MAP, map_depth=MAP, feature_size=C, grid_resolution=RES)
+    lay = ResNetProjectionLayer(camera_height=Hc, camera_width=Wc, feature_extractor=extractor, **kw).to(device)
+    assert (lay.camera_height, lay.camera_width) == (Hc // 4, Wc // 4) and tuple(lay.rays.shape) == (12, 16, 3)
+    ol = orc.RefProjectionLayer(camera_height=Hc // 4, camera_width=Wc // 4, **kw)
+    for t in range(3):
+        rgb = torch.rand(Hc, Wc, 3, generator=g).numpy()
+        depth = (0.3 + 1.5 * torch.rand(Hc, Wc, 1, generator=g)).numpy()
+        pose = dict(position=[0.1 * t, -0.1, 0.2], yaw=0.5 + t, elevation=-0.4)
+        lay.update(dict(pose, depth=depth, rgb=rgb))
+        ol.update(dict(pose, depth=torch.tensor(depth)[2::4, 2::4], features=extractor(rgb)))
+    assert_map_close(lay.data.cpu().numpy(), ol.data.numpy())
