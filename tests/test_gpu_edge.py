@@ -120,3 +120,23 @@ def test_functional_update_feature_map_labels_and_ones(device):
     orc.update_feature_map(*ind, *rat, torch.ones(n, 1), want, interpolation_weight=1.0)
     assert_map_close(got.cpu().numpy(), want.numpy())
     update_feature_map(*[t[:0].to(device) for t in ind], *[t[:0].to(device) for t in rat], None, got, 1.0)   # empty
+
+
+def test_stage_timing_diagnostics(device):
+    """mf_profile_enable / mf_profile_read: per-stage HIP-event times of the most recent calls."""
+    from mass_amd import _lib
+    kw = dict(camera_height=24, camera_width=32, map_height=32, map_width=32, map_depth=16, feature_size=3,
+              grid_resolution=0.1)
+    from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+    lay = BaseProjectionLayer(**kw).to(device)
+    fr = random_frames(4, 24, 32, 3, seed=1)
+    ms = np.zeros(5, np.float32)
+    assert _lib.lib.mf_profile_read(0, ms.ctypes.data) < 0          # nothing recorded yet
+    _lib.check(_lib.lib.mf_profile_enable(1))
+    for t in range(3):
+        lay.update({k: v[t] for k, v in fr.items() if k != "semantic"})
+    assert _lib.check(_lib.lib.mf_profile_read(2, ms.ctypes.data)) == 3
+    assert (ms >= 0).all() and ms[4] >= ms[3] > 0 and abs(ms[:4].sum() - ms[4]) < 0.05 * ms[4] + 0.01
+    _lib.check(_lib.lib.mf_profile_enable(0))
+    lay.update({k: v[3] for k, v in fr.items() if k != "semantic"})
+    assert _lib.lib.mf_profile_read(3, ms.ctypes.data) < 0          # not recorded while disabled
