@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — RGB-D frames/s fused into a 256^3 x 54-class semantic voxel map.
 
-    python bench.py --gpus N --steps K --warmup W        (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 without WORLD_SIZE in the environment starts
+N fresh rank processes (python -m torch.distributed.run) BEFORE this process has
+made any GPU call and relays rank 0's JSON line; under torch.distributed.run it
+is one rank of the job (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).
 
 A step is one pass of the hot path (mf_fuse_frames: unproject + bin + tile
 scatter + blend, sequential semantics = 64 successive layer.update() calls)
@@ -11,11 +15,22 @@ resident in HBM (BASELINE.json configs[1], distribution A of SURVEY 8(d)).
 Each rank owns its own map and its own frames (independent episodes, weak
 scaling); the only collective is the final metrics all-reduce.
 
+Roofline accounting: a launch keeps every map tile in LDS
+across its 64 frames, so the bytes that MUST move per launch are
+    inputs  B*H*W*(4 + 1)    +    |union of the frames' 8-corner footprints| * C * 4 * 2
+(each touched voxel read once and written once).  `roofline.frac` prices the
+tile kernel against exactly that (never above 1); SURVEY 8(d)'s per-frame figure
+(a read-modify-write per frame) is reported as `per_frame_model`, informational.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,20 +42,50 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 H, W, C, MAP, BATCH = 480, 640, 54, 256, 64
+KERNEL_SOURCES = ("mass_amd/csrc/fuse.hip", "mass_amd/csrc/geometry.h")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--workload", default="distA", choices=["distA", "room"])
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the batch timed through the CPU oracle")
+    ap.add_argument("--mode", default="sequential", choices=["sequential", "merged"])
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames per repetition of the CPU oracle (1 warm + 3 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the other SURVEY 8(d) workloads (rank 0, N = 1)")
+    ap.add_argument("--rank-seed-stride", type=int, default=-1,
+                    help="rank r draws its frames from seeds r*stride.. (default: the batch size, i.e. disjoint "
+                         "episodes per rank; 0 gives every rank the same frames, used by the 2-rank rehearsal test)")
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------------------------
+# N > 1 from a plain `python bench.py --gpus N`: start the ranks as children (no GPU call here)
+# ----------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """The reference shards episodes over separate OS processes (agent.py:154-155,795-800);
+    so does this: N children, one per GPU, started before the parent touches the device."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+# ----------------------------------------------------------------------------------------------
+# workload helpers
+# ----------------------------------------------------------------------------------------------
 def make_frames(workload, n, seed0):
     from mass_amd.episodes import dist_a_frames, room_trajectory
     if workload == "distA":
@@ -49,12 +94,13 @@ def make_frames(workload, n, seed0):
     return {k: tr[k] for k in ("position", "yaw", "elevation", "depth", "semantic")}
 
 
-def touched_per_frame(lay, poses, depth):
-    """T_f = distinct voxels in the 8-corner footprint of frame f (the T of the
-    algorithmic-bytes formula), from the HIP integer outputs (tests prove them
-    bit-identical to the oracle's).  Not timed."""
+def footprints(lay, poses, depth):
+    """Per frame T_f = distinct voxels in the frame's 8-corner footprint, and the size of the
+    UNION of those sets over the batch (the voxels one fused launch has to read and write),
+    from the HIP integer outputs (tests prove them bit-identical to the oracle's).  Not timed."""
     from mass_amd.utils.projection import unproject_bin
     s = (lay.map_height, lay.map_width, lay.map_depth)
+    seen = torch.zeros(s[0] * s[1] * s[2], dtype=torch.bool, device=depth.device)
     T, valid_pts = [], 0
     for f in range(depth.shape[0]):
         ix, iy, iz, rx, ry, rz, valid = unproject_bin(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays,
@@ -66,66 +112,273 @@ def touched_per_frame(lay, poses, depth):
             lo = torch.where(r < 0.5, (k - 1).clamp(min=0), k)
             hi = torch.where(r < 0.5, k, (k + 1).clamp(max=size - 1))
             axes.append((lo, hi))
-        ids = torch.cat([((a * s[1] + b) * s[2] + c) for a in axes[0] for b in axes[1] for c in axes[2]])
-        T.append(int(torch.unique(ids).numel()))
-    return T, valid_pts
+        ids = torch.unique(torch.cat([((a * s[1] + b) * s[2] + c) for a in axes[0] for b in axes[1] for c in axes[2]]))
+        T.append(int(ids.numel()))
+        seen[ids] = True
+    return T, valid_pts, int(seen.sum())
 
 
-def cpu_baseline(frames, n):
-    """The oracle (oracle/massref.c, scalar C port of the reference algorithm,
-    1 thread) on the first n frames of rank 0's batch, sequential, same map size."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(frames, per_rep, reps=3):
+    """The oracle (oracle/massref.c, scalar C port of the reference algorithm, 1 thread) on the
+    first (1 + reps) * per_rep frames of rank 0's batch, sequential, same map size: one warm
+    repetition, then `reps` timed ones; the median rate is reported.  Returns the baseline
+    record and the oracle layer (its map is what the GPU parity check compares with)."""
     from oracle import massref as orc
     lay = orc.RefProjectionLayer(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
                                  feature_size=C, grid_resolution=0.05)
-    obs = []
-    for f in range(n):
-        obs.append(dict(position=frames["position"][f], yaw=frames["yaw"][f], elevation=frames["elevation"][f],
-                        depth=frames["depth"][f],
-                        features=torch.nn.functional.one_hot(frames["semantic"][f].long(), C).float()))
+    n = (1 + reps) * per_rep
+    obs = [dict(position=frames["position"][f], yaw=frames["yaw"][f], elevation=frames["elevation"][f],
+                depth=frames["depth"][f],
+                features=torch.nn.functional.one_hot(frames["semantic"][f].long(), C).float()) for f in range(n)]
+    rates, total = [], 0.0
+    for r in range(1 + reps):
+        t0 = time.perf_counter()
+        for o in obs[r * per_rep:(r + 1) * per_rep]:
+            lay.update(o)
+        dt = time.perf_counter() - t0
+        total += dt
+        if r > 0:
+            rates.append(per_rep / dt)
+    rec = dict(value=statistics.median(rates), unit="frames/s", cores=1, kind="port",
+               reps=reps, rates=[round(x, 4) for x in rates], cpu_model=cpu_model(), host_cpus=os.cpu_count(),
+               torch_threads=torch.get_num_threads(), torch=torch.__version__,
+               sample=f"frames {per_rep}..{n - 1} of rank 0's batch through oracle/massref.c (bin_rays + "
+                      f"update_feature_map on one-hot fp32 features as the reference builds them), sequential "
+                      f"onto one {MAP}^3 x {C} map: 1 warm + {reps} timed repetitions of {per_rep} frames, median; "
+                      f"{total:.1f} s of CPU work, single thread (scalar port)",
+               reference_in_build_container="0.52 frames/s (the reference's own torch CPU path, 8 threads, "
+                                            "256^3 x 54; SURVEY section 6)")
+    return rec, lay, n
+
+
+def parity_vs_oracle(lay_kw, frames, n, ref_layer, dev):
+    """Untimed: the first n frames of the batch through the HIP pipeline onto a fresh map,
+    compared with the oracle map cpu_baseline() built from the same frames."""
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    lay = SemanticProjectionLayer(**lay_kw).to(dev)
+    lay.update_batch(dict(position=frames["position"][:n], yaw=frames["yaw"][:n], elevation=frames["elevation"][:n],
+                          depth=frames["depth"][:n].to(dev), semantic=frames["semantic"][:n].to(dev)), sequential=True)
+    occ_equal, ok, rel, occupied = True, True, 0.0, 0
+    for y0 in range(0, MAP, 32):                       # compared on the device, slab by slab, in fp64
+        got = lay.data[y0:y0 + 32].to(torch.float64)
+        want = ref_layer.data[y0:y0 + 32].to(dev).to(torch.float64)
+        occ_equal &= bool(torch.equal(got != 0, want != 0))
+        err = (got - want).abs()
+        ok &= bool((err <= 1e-4 * want.abs() + 1e-6).all())
+        rel = max(rel, float((err / (want.abs() + 1e-6)).max()))
+        occupied += int((want != 0).any(-1).sum())
+    del lay
+    return dict(parity_checked_frames=n, occupancy_bit_exact=occ_equal, within_tolerance=ok,
+                tolerance="|got - want| <= 1e-4 |want| + 1e-6", max_scaled_err=rel, occupied_voxels=occupied,
+                note="GPU map after the first n frames (one sequential launch) vs the oracle map of the same frames")
+
+
+def sources_sha():
+    h = hashlib.sha256()
+    for p in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, p), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(key):
+    """HBM bytes per launch from the rocprofv3 PMC passes (profiles/traffic.json), only if they
+    were measured on the kernel sources this run uses."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
+        return None, "profiles/traffic.json missing"
+    with open(tfile) as f:
+        t = json.load(f)
+    if t.get("kernel_sources_sha16") != sources_sha():
+        return None, (f"profiles/traffic.json was measured on kernel sources {t.get('kernel_sources_sha16')}, "
+                      f"this run uses {sources_sha()}: not reported")
+    return t.get(key), t.get("_source")
+
+
+def timed_fuse(lay, poses, depth, label, sequential, steps, warmup):
+    """steps calls of the fused pipeline on resident inputs; returns (wall s, stage ms [steps, 5])."""
+    from mass_amd import _lib
+    from mass_amd.utils.projection import fuse_frames
+
+    def step():
+        fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, label, lay.data,
+                    interpolation_weight=lay.interpolation_weight, sequential=sequential, workspace=lay._workspace)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib.mf_profile_enable(1))
+    n_prof = min(steps, 256)
     t0 = time.perf_counter()
-    for o in obs:
-        lay.update(o)
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="frames/s", cores=1, kind="port",
-                sample=f"first {n} frames of rank 0's batch through oracle/massref.c (bin_rays + "
-                       f"update_feature_map, one-hot fp32 features as the reference builds them), "
-                       f"sequential, {MAP}^3 x {C}, {dt:.1f} s"), lay
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = np.zeros((n_prof, 5), np.float32)
+    for k in range(n_prof):
+        _lib.check(_lib.lib.mf_profile_read(k, ms[k].ctypes.data))
+    _lib.check(_lib.lib.mf_profile_enable(0))
+    return wall, ms
 
 
-def main():
-    args = parse()
+def stage_dict(ms):
+    m = ms.mean(0)
+    return {"zero+count": float(m[0]), "scan": float(m[1]), "scatter": float(m[2]), "fuse_tiles": float(m[3]),
+            "call": float(m[4])}
+
+
+def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
+    """The other workloads SURVEY 8(d) specifies, each measured here on the same binary
+    (rank 0, N = 1, after the headline; none of them enters `value`)."""
+    from mass_amd.episodes import room_trajectory
+    from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+    from mass_amd.nn.applications.occupancy_projection_layer import OccupancyProjectionLayer
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    from mass_amd.utils.experimentation import pairwise_distance, linear_sum_assignment
+    out = {}
+
+    def batch_run(name, frames, poses, depth, label, sequential, steps=20):
+        lay = SemanticProjectionLayer(**lay_kw).to(dev)
+        wall, ms = timed_fuse(lay, poses, depth, label, sequential, steps, 3)
+        T, valid, union = footprints(lay, poses, depth)
+        B = depth.shape[0]
+        step_bytes = B * H * W * 5 + union * C * 8
+        st = stage_dict(ms)
+        out[name] = dict(frames_per_s=B * steps / wall, ms_per_step=wall / steps * 1e3, stage_ms=st,
+                         union_voxels=union, touched_voxels_per_frame_mean=float(np.mean(T)),
+                         algorithmic_bytes_per_launch=step_bytes,
+                         frac_of_hbm_peak_kernel=union * C * 8 / (st["fuse_tiles"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         frac_of_hbm_peak_step=step_bytes / (st["call"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         mode="sequential" if sequential else "merged")
+        del lay
+
+    # configs[1], distribution A, merged mode (the functional API's batch semantics, SURVEY A.6)
+    batch_run("distA_merged_b64", frames_a, poses_a, depth_a, label_a, False)
+
+    # configs[1], distribution B: 64 consecutive frames of the box-room trajectory, sequential
+    tr = room_trajectory(BATCH, H, W, seed=0)
+    probe = SemanticProjectionLayer(**lay_kw).to(dev)
+    poses_b = probe._poses(tr["position"], tr["yaw"], tr["elevation"])
+    del probe
+    depth_b = tr["depth"].to(dev).reshape(BATCH, H, W).contiguous()
+    label_b = tr["semantic"].to(dev).contiguous()
+    batch_run("distB_sequential_b64", tr, poses_b, depth_b, label_b, True)
+    del depth_b, label_b
+
+    # configs[2]: 300-frame room trajectory, three maps updated per frame through layer.update()
+    # (occupancy C = 1, semantic C = 54, "RGB" C = 3 dense), as agent.py:107-111 drives them
+    n3 = 300
+    tr = room_trajectory(n3, H, W, seed=1)
+    occ = OccupancyProjectionLayer(**{k: v for k, v in lay_kw.items() if k != "feature_size"}).to(dev)
+    sem = SemanticProjectionLayer(**lay_kw).to(dev)
+    rgb = BaseProjectionLayer(**dict(lay_kw, feature_size=3)).to(dev)
+    d_dev, s_dev, c_dev = tr["depth"].to(dev), tr["semantic"].to(dev)[..., None], tr["rgb"].to(dev)
+
+    def run_traj(host_fed):
+        for lay in (occ, sem, rgb):
+            lay.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(n3):
+            if host_fed:      # numpy observations, as the simulator hands them over (PCIe inclusive)
+                o = dict(position=tr["position"][t].numpy(), yaw=float(tr["yaw"][t]), elevation=float(tr["elevation"][t]),
+                         depth=d_np[t])
+                occ.update(o)
+                sem.update(dict(o, semantic=s_np[t]))
+                rgb.update(dict(o, features=c_np[t]))
+            else:
+                o = dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t], depth=d_dev[t])
+                occ.update(o)
+                sem.update(dict(o, semantic=s_dev[t]))
+                rgb.update(dict(o, features=c_dev[t]))
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    run_traj(False)
+    dt = min(run_traj(False) for _ in range(2))
+    d_np, s_np, c_np = tr["depth"].numpy(), tr["semantic"].numpy()[..., None].astype(np.int64), tr["rgb"].numpy()
+    dt_host = run_traj(True)
+    out["config3_trajectory_300x3maps"] = dict(
+        frames_per_s=n3 / dt, ms_per_frame_3_maps=dt / n3 * 1e3, updates_per_s=3 * n3 / dt,
+        host_fed_frames_per_s=n3 / dt_host, host_fed_ms_per_frame=dt_host / n3 * 1e3,
+        note="per-frame layer.update() on occupancy (C=1), semantic (C=54 labels) and RGB (C=3 dense fp32) maps, "
+             "256^3 each, sequential; frames_per_s with observations resident in HBM, host_fed_* with numpy "
+             "observations uploaded per call (PCIe inclusive, int64 label image as the simulator produces it)")
+    del occ, sem, rgb, d_dev, s_dev, c_dev
+
+    # configs[3]: matching, 200 x 200 instance pairs, 1024-d (experimentation.py:261-287)
+    g = torch.Generator().manual_seed(0)
+    f0 = torch.randn(200, 1024, generator=g).to(dev)
+    f1 = torch.randn(200, 1024, generator=torch.Generator().manual_seed(1)).to(dev)
+    res = {}
+    for metric in ("l2", "l2_gemm"):
+        for _ in range(3):
+            pairwise_distance(f0, f1, metric)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            cost = pairwise_distance(f0, f1, metric)
+        e1.record()
+        torch.cuda.synchronize()
+        res[f"pairwise_{metric}_ms"] = e0.elapsed_time(e1) / 50
+    cost_h = cost.cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        rows, cols = linear_sum_assignment(cost_h)
+    res["assignment_host_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(20):
+        c2 = pairwise_distance(f0, f1, "l2")
+        linear_sum_assignment(c2)
+    res["end_to_end_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    res["note"] = ("82 MFLOP contraction: launch-latency bound, no roofline claim (SURVEY 8d); l2 = the reference's "
+                   "difference form, l2_gemm = norm expansion on fp32 MFMA; assignment on the host like the reference")
+    out["config4_matching_200x200x1024"] = res
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+def run_rank(args):
     from mass_amd import distributed as D
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_env == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     # nccl == RCCL on ROCm.  MF_BENCH_BACKEND=gloo is a rehearsal knob for boxes with fewer GPUs
     # than ranks (ranks then share device rank % device_count); the driver never sets it.
     backend = os.environ.get("MF_BENCH_BACKEND", "nccl")
     n_dev = max(torch.cuda.device_count(), 1)
-    if backend == "nccl":
-        rank, world, local_rank = D.init_from_env(backend="nccl")
-    else:
-        rank, world, local_rank = D.init_from_env(backend=backend)
+    rank, world, local_rank = D.init_from_env(backend=backend)
+    if backend != "nccl":
         local_rank %= n_dev
     args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from mass_amd import _lib
     from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
 
-    lay = SemanticProjectionLayer(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
-                                  feature_size=C, grid_resolution=0.05).train().to(dev)
-    frames = make_frames(args.workload, args.batch, seed0=rank * args.batch)
+    lay_kw = dict(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
+                  feature_size=C, grid_resolution=0.05)
+    lay = SemanticProjectionLayer(**lay_kw).train().to(dev)
+    stride = args.batch if args.rank_seed_stride < 0 else args.rank_seed_stride
+    frames = make_frames(args.workload, args.batch, seed0=rank * stride)
     poses = lay._poses(frames["position"], frames["yaw"], frames["elevation"])
     depth = frames["depth"].to(dev).reshape(args.batch, H, W).contiguous()
     label = frames["semantic"].to(dev).contiguous()
+    sequential = args.mode == "sequential"
 
+    from mass_amd import _lib
     from mass_amd.utils.projection import fuse_frames
 
     def step():
         fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, label, lay.data,
-                    interpolation_weight=lay.interpolation_weight, sequential=True, workspace=lay._workspace)
+                    interpolation_weight=lay.interpolation_weight, sequential=sequential, workspace=lay._workspace)
 
     def barrier():
         torch.cuda.synchronize()
@@ -153,61 +406,86 @@ def main():
 
     wall_max = D.max_over_ranks(wall)
 
-    # ---- algorithmic bytes of one step: sum_f H*W*(4+1) + T_f*C*4*2 ------------
-    T, valid_pts = touched_per_frame(lay, poses, depth)
-    alg_bytes = sum(H * W * (4 + 1) + Tf * C * 4 * 2 for Tf in T)
+    # ---- bytes one launch has to move: inputs + union of the touched voxels, read + written once ----
+    T, valid_pts, union = footprints(lay, poses, depth)
+    input_bytes = args.batch * H * W * (4 + 1)
+    tile_bytes = union * C * 4 * 2
+    per_frame_model = sum(H * W * (4 + 1) + Tf * C * 4 * 2 for Tf in T)       # SURVEY 8(d), informational
     # the one data collective of the run: SUM all-reduce of the per-rank counters (RCCL)
     metrics = D.reduce_metrics(dict(frames=args.batch * args.steps, valid_points=valid_pts * args.steps,
-                                    touched_voxels=sum(T) * args.steps,
+                                    touched_voxels=sum(T) * args.steps, union_voxels=union,
                                     map_abs_sum=float(lay.data.abs().sum(dtype=torch.float64))))
 
     if rank == 0:
         frames_total = args.batch * args.steps * world
         ms_per_step = wall_max / args.steps * 1e3
-        fuse_ms = float(stage_ms[:, 3].mean())
-        step_ms = float(stage_ms[:, 4].mean())
-        achieved = alg_bytes / (fuse_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            with open(tfile) as f:
-                traffic = json.load(f).get(f"{args.workload}_b{args.batch}")
+        st = stage_dict(stage_ms)
+        fuse_ms, step_ms = st["fuse_tiles"], st["call"]
+        achieved = tile_bytes / (fuse_ms * 1e-3) / 1e9
+        traffic, traffic_src = recorded_traffic(f"{args.workload}_{args.mode}_b{args.batch}")
+        dist_name = "A (depth 0.5+4.5U, random poses)" if args.workload == "distA" else "B (box room trajectory)"
         out = {
             "metric": "RGB-D frames/s fused into 256^3 semantic voxel map",
             "value": frames_total / wall_max, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {args.batch} x 480x640 depth + u8 54-class labels -> 256^3 x 54 "
-                                   f"fp32 map at 0.05 m, distribution {'A (depth 0.5+4.5U, random poses)' if args.workload == 'distA' else 'B (box room trajectory)'}, "
-                                   f"sequential blend (= {args.batch} layer.update calls), one map per GPU",
-                       "frames_per_step": args.batch, "map": [MAP, MAP, MAP, C], "mode": "sequential"},
-            "roofline": {"bound": "hbm", "kernel": "fuse_tiles_kernel<1>", "achieved": achieved,
+                                   f"fp32 map at 0.05 m, distribution {dist_name}, {args.mode} blend"
+                                   f"{' (= %d layer.update calls)' % args.batch if sequential else ''}, one map per GPU",
+                       "frames_per_step": args.batch, "map": [MAP, MAP, MAP, C], "mode": args.mode},
+            "roofline": {"bound": "hbm", "kernel": "fuse_tiles_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": fuse_ms,
-                         "traffic_GBps": (traffic / (fuse_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": tile_bytes, "kernel_ms": fuse_ms,
+                         "union_voxels": union,
                          "traffic_frac_of_peak": (traffic / (fuse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "note": "algorithmic bytes = sum over the launch's frames of H*W*5 + T_f*C*8 (per-frame "
-                                 "RMW of every touched voxel); the kernel keeps map tiles in LDS across the 64 "
-                                 "frames, so HBM sees each touched voxel once per launch: `traffic` (rocprofv3 PMC, "
-                                 "profiles/) is the bytes that actually moved, and frac > 1 means the launch beats what "
-                                 "a per-frame implementation could do at 100% of HBM peak"},
-            "roofline_step": {"achieved": alg_bytes / (step_ms * 1e-3) / 1e9, "frac": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "step_ms_gpu": step_ms, "stage_ms": {"zero+count": float(stage_ms[:, 0].mean()),
-                                                                   "scan": float(stage_ms[:, 1].mean()),
-                                                                   "scatter": float(stage_ms[:, 2].mean()),
-                                                                   "fuse_tiles": fuse_ms}},
+                         "note": "algorithmic bytes of the tile kernel = union over the launch's frames of the touched "
+                                 "voxels x C x 4 B x (1 read + 1 write): the launch keeps tiles in LDS across its "
+                                 "frames, so each touched voxel has to cross HBM once each way; kernel_ms = mean "
+                                 "HIP-event time of fuse_tiles over the timed steps (mf_profile_*, on the launch stream)"},
+            "roofline_step": {"achieved": (input_bytes + tile_bytes) / (step_ms * 1e-3) / 1e9,
+                              "frac": (input_bytes + tile_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_step": input_bytes + tile_bytes,
+                              "step_ms_gpu": step_ms, "stage_ms": st},
+            "per_frame_model": {"bytes_per_step": per_frame_model,
+                                "equivalent_GBps": per_frame_model / (step_ms * 1e-3) / 1e9,
+                                "note": "SURVEY 8(d): sum_f H*W*5 + T_f*C*8, i.e. what B separate layer.update() calls "
+                                        "would have to move; informational only (a fused launch moves less), not a "
+                                        "roofline fraction"},
             "touched_voxels_per_frame_mean": float(np.mean(T)),
             "gpu_ms_total": gpu_ms,
+            "kernel_sources_sha16": sources_sha(),
             "metrics_allreduce": metrics,
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, _ = cpu_baseline(frames, args.cpu_frames)
-            cb["host_cpus"] = os.cpu_count()
+            cb, ref_layer, n_ref = cpu_baseline(frames, args.cpu_frames)
             out["cpu_baseline"] = cb
+            if sequential:
+                out["parity"] = parity_vs_oracle(lay_kw, frames, n_ref, ref_layer, dev)
+            del ref_layer
+        if world == 1 and not args.no_extras:
+            del lay
+            torch.cuda.empty_cache()
+            fa = frames if args.workload == "distA" else make_frames("distA", args.batch, 0)
+            if args.workload != "distA":
+                probe = SemanticProjectionLayer(**lay_kw).to(dev)
+                poses = probe._poses(fa["position"], fa["yaw"], fa["elevation"])
+                del probe
+                depth = fa["depth"].to(dev).reshape(args.batch, H, W).contiguous()
+                label = fa["semantic"].to(dev).contiguous()
+            out["other_workloads"] = extra_workloads(lay_kw, dev, fa, poses, depth, label)
         print(json.dumps(out), flush=True)
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -131,29 +131,39 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         shape = list(fm.shape[:-2]) + [1, fm.shape[-1]]
         return torch.gather(fm, -2, idx.expand(*shape)).squeeze(-2)
 
+    def _refresh_bounds(self):
+        """World-space clamp limits: midpoints of the outermost voxels per axis (xyz).  They
+        depend only on the edges, so they are rebuilt with them (ctor, reset, device moves)."""
+        edges = (self.bins_x, self.bins_y, self.bins_z)
+        self._world_lo = torch.stack([(e[0] + e[1]) / 2 for e in edges])
+        self._world_hi = torch.stack([(e[-1] + e[-2]) / 2 for e in edges])
+        self._bounds_key = tuple((e.data_ptr(), e._version) for e in edges)
+
+    def _bounds(self):
+        key = tuple((e.data_ptr(), e._version) for e in (self.bins_x, self.bins_y, self.bins_z))
+        if getattr(self, "_bounds_key", None) != key:
+            self._refresh_bounds()
+        return self._world_lo, self._world_hi
+
     def clamp_to_world(self, coords):
-        """Clamp xyz world coordinates to the centres of the outermost voxels
-        (base_projection_layer.py:381-416)."""
+        """xyz (or xy) world coordinates limited to the span between the centres of the first
+        and last voxel of every axis (base_projection_layer.py:381-416)."""
         coords = torch.as_tensor(coords, dtype=torch.float32, device=self.data.device)
-        upper = torch.stack([(self.bins_x[-1] + self.bins_x[-2]) / 2,
-                             (self.bins_y[-1] + self.bins_y[-2]) / 2,
-                             (self.bins_z[-1] + self.bins_z[-2]) / 2])
-        lower = torch.stack([(self.bins_x[0] + self.bins_x[1]) / 2,
-                             (self.bins_y[0] + self.bins_y[1]) / 2,
-                             (self.bins_z[0] + self.bins_z[1]) / 2])
-        shape = [1 for _ in coords.shape[:-1]] + [3]
-        return coords.clamp(min=lower.view(*shape)[..., :coords.shape[-1]],
-                            max=upper.view(*shape)[..., :coords.shape[-1]])
+        lo, hi = self._bounds()
+        k = coords.shape[-1]
+        return torch.minimum(torch.maximum(coords, lo[:k]), hi[:k])
 
     def clamp_to_map(self, coords):
-        """Clamp xyz map coordinates to [0, size - 1] (base_projection_layer.py:418-450)."""
-        kwargs = dict(dtype=coords.dtype, device=self.data.device)
-        coords = torch.as_tensor(coords, **kwargs)
-        lower = torch.tensor([0, 0, 0], **kwargs)
-        upper = torch.tensor([self.map_width - 1, self.map_height - 1, self.map_depth - 1], **kwargs)
-        shape = [1 for _ in coords.shape[:-1]] + [3]
-        return coords.clamp(min=lower[:coords.shape[-1]].view(*shape),
-                            max=upper[:coords.shape[-1]].view(*shape))
+        """xyz map coordinates limited to [0, size - 1] per axis (base_projection_layer.py:418-450).
+        Like the reference, only 3-vectors are accepted: its xy form reshapes two limits into
+        three and raises RuntimeError, which callers of map_to_world(xy) see as well."""
+        coords = torch.as_tensor(coords, device=self.data.device)
+        if coords.shape[-1] != 3:
+            raise RuntimeError(f"clamp_to_map needs xyz coordinates, got last dimension {coords.shape[-1]} "
+                               "(the reference fails the same way on xy input)")
+        last = torch.tensor([self.map_width - 1, self.map_height - 1, self.map_depth - 1],
+                            dtype=coords.dtype, device=coords.device)
+        return torch.minimum(coords.clamp(min=0), last)
 
     def map_to_world(self, coords):
         """xyz map coordinates -> world coordinates by interpolating between

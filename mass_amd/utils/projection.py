@@ -127,7 +127,9 @@ class Workspace:
         self.buf = None
 
     def get(self, nbytes, device):
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+        """(256-byte aligned pointer, usable bytes >= nbytes).  The buffer carries 256 spare
+        bytes for the alignment, so the usable capacity is numel - 256."""
+        if self.buf is None or self.buf.numel() - 256 < nbytes or self.buf.device != device:
             self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
         base = self.buf.data_ptr()
         return _lib.c_void_p((base + 255) // 256 * 256), self.buf.numel() - 256

@@ -66,3 +66,22 @@ def assert_map_close(got, want, rtol=1e-4, atol=1e-6, what="map"):
     bad = err > bound
     assert not bad.any(), (f"{what}: {int(bad.sum())} entries out of tolerance, "
                            f"max abs err {err.max():.3e}, max rel {np.max(err / (np.abs(want) + 1e-30)):.3e}")
+
+
+def assert_map_close_device(got, want, rtol=1e-4, atol=1e-6, what="map", slab=32):
+    """assert_map_close for full-size maps (3.6 GB at 256^3 x 54): `got` is the device map,
+    `want` the oracle's CPU tensor; compared on the device slab by slab in fp64."""
+    import torch
+    assert tuple(got.shape) == tuple(want.shape)
+    occupied = 0
+    for y0 in range(0, got.shape[0], slab):
+        g = got[y0:y0 + slab].to(torch.float64)
+        w = want[y0:y0 + slab].to(got.device).to(torch.float64)
+        diff_occ = int(((g != 0) != (w != 0)).sum())
+        assert diff_occ == 0, f"{what}: occupancy differs in {diff_occ} entries (rows {y0}..)"
+        err = (g - w).abs()
+        bad = err > rtol * w.abs() + atol
+        assert not bool(bad.any()), (f"{what}: {int(bad.sum())} entries out of tolerance in rows {y0}.., "
+                                     f"max abs err {float(err.max()):.3e}")
+        occupied += int((w != 0).any(-1).sum())
+    return occupied

@@ -106,3 +106,15 @@ def test_lsa_rejects_nan_and_handles_empty():
         lsa(np.array([[0.0, -np.inf], [1.0, 2.0]]))
     r, c = lsa(np.zeros((0, 3)))
     assert r.size == 0 and c.size == 0
+
+
+def test_workspace_regrows_when_the_need_grows_by_one_alignment_unit():
+    """a need that grows by exactly 256 bytes must not be served from the old buffer."""
+    import torch
+    from mass_amd.utils.projection import Workspace
+    ws = Workspace()
+    cpu = torch.device("cpu")
+    for need in (102400, 102656, 102912, 1024, 103168):
+        p, cap = ws.get(need, cpu)
+        assert cap >= need and p.value % 256 == 0
+        assert p.value + cap <= ws.buf.data_ptr() + ws.buf.numel()

@@ -74,8 +74,12 @@ def test_find_feature_map_on_cpu_and_cache_invalidation(device):
     for fa, fb in zip(a[3], b[3]):
         np.testing.assert_allclose(fa.cpu().numpy(), fb.cpu().numpy(), rtol=5e-5, atol=1e-6)
     # the cached class images must follow the map
-    n0 = len(a[0])
+    before = sem.class_images(0.0)[..., 1].clone()
+    key0 = sem._class_images[0]
     sem.update(dict(position=[0.0, 0.0, 0.0], yaw=0.3, elevation=-0.4, depth=np.full((24, 32, 1), 1.0, np.float32),
                     semantic=np.full((24, 32, 1), 1, np.int64)))
-    assert len(sem.find(1, contour_padding=0, confidence_threshold=0.0)[0]) != n0 or True
-    assert sem._class_images[0][0] == sem._map_version
+    sem.find(1, contour_padding=0, confidence_threshold=0.0)
+    after = sem.class_images(0.0)[..., 1]
+    assert sem._class_images[0] != key0 and sem._class_images[0][0] == sem._map_version
+    # the frame paints class 1 onto columns that had none: the cached image must have followed
+    assert int(after.sum()) > int(before.sum()) and bool((after | ~before).all())
