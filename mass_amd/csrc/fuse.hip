@@ -34,6 +34,8 @@
 // Tuning / diagnostics, all off by default: MF_TILE="s0 s1 s2 threads [gc]" overrides the tile
 // shape, MF_STAMPS=1 prints the share of each phase of the tile kernel (dev builds of bench runs).
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
 #include "geometry.h"
 
@@ -483,8 +485,8 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     float *osc = sc + TV;                          // [TV] prod a_f: factor of the old map value
     int *offs2 = (int *)(osc + TV);                // [2][MAX_GROUPS + 1] bucket starts: this tile / next tile
     int *cb = offs2 + 2 * (MAX_GROUPS + 1);        // [MAX_CHUNK + 1] entry offsets of the chunk's frames
-    int *misc = cb + MAX_CHUNK + 1;                // [0] first tile, [1] non-empty frame count, [2] next tile
-    unsigned short *ne = (unsigned short *)(misc + 4);   // [MAX_GROUPS] non-empty frames, ascending
+    int *misc = cb + MAX_CHUNK + 1;                // [0] first tile, [1] non-empty frame count, [2] tile after next, [3] second tile, [4..7] class sizes
+    unsigned short *ne = (unsigned short *)(misc + 8);   // [MAX_GROUPS] non-empty frames, ascending
     unsigned char *touched = (unsigned char *)(ne + MAX_GROUPS);   // [TV]
     const int G = P.G;
     const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
@@ -495,15 +497,16 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     // The work list is walked with a ticket counter.  Everything the NEXT tile needs before
     // its first pass (ticket, tile id, bucket offsets: three dependent global round trips)
     // is fetched while the current tile is being processed.
-    int ccount[TILE_CLASSES];
-#pragma unroll
-    for (int c = 0; c < TILE_CLASSES; ++c) ccount[c] = P.ticket[1 + c];
+    // Tickets are drawn three tiles ahead: while tile i is processed, the bucket offsets of tile
+    // i+1 are fetched, the id of tile i+2 is looked up (ticket -> work list entry) and the ticket
+    // of tile i+3 is drawn, so none of these dependent global round trips is ever waited for.
     auto resolve = [&](int idx) {          // ticket -> (class, position) -> tile id, -1 past the end
         int tile_id = -1;
 #pragma unroll
         for (int c = 0; c < TILE_CLASSES; ++c) {
-            if (tile_id < 0 && idx >= 0 && idx < ccount[c]) tile_id = P.active[c * P.n_tiles + idx];
-            idx -= ccount[c];
+            const int cc = misc[4 + c];                 // tiles in class c (copied from P.ticket[1 + c] once)
+            if (tile_id < 0 && idx >= 0 && idx < cc) tile_id = P.active[c * P.n_tiles + idx];
+            idx -= cc;
         }
         return tile_id;
     };
@@ -523,9 +526,23 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             if (g <= G) dst[g] = o[q];
         }
     };
-    if (tid == 0) misc[0] = resolve(atomicAdd(P.ticket, 1));
+    // tid 0 advances this pipeline once per tile, right after the workgroup's only full vmcnt(0)
+    // wait (the old-map preload): nothing else is outstanding there, so reading the results of the
+    // loads issued one tile earlier costs no wait of its own (vmcnt retires in order: waiting for an
+    // old load at any other point would also wait for every younger load and store of the wave).
+    int idx_pend = -1, act_pend = -1;                   // ticket drawn / work list entry being loaded
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) misc[4 + c] = P.ticket[1 + c];
+        const int i0 = atomicAdd(P.ticket, 1), i1 = atomicAdd(P.ticket, 1), i2 = atomicAdd(P.ticket, 1);
+        misc[0] = resolve(i0);
+        misc[3] = resolve(i1);
+        act_pend = resolve(i2);
+        idx_pend = atomicAdd(P.ticket, 1);
+    }
     __syncthreads();
     int tile = misc[0];
+    int tile_next = misc[3];
     if (tile >= 0) {
         int o[OPT];
         load_offs(tile, o);
@@ -547,10 +564,8 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     if (tile >= 0) prefetch_entries(offs2);
 
     while (tile >= 0) {
-        int idx_next = -1;
-        if (tid == 0) idx_next = atomicAdd(P.ticket, 1);       // consumed after pass 1
         int onext[OPT];
-        int tile_next = -1;
+        if (tile_next >= 0) load_offs(tile_next, onext);      // in flight during the first chunk
         const int *offs = offs2 + buf * (MAX_GROUPS + 1);
         MF_STAMP(0)
         const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
@@ -636,8 +651,14 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                         });
                     }
             }
-            if (c0 == 0 && tid == 0) misc[2] = resolve(idx_next);
-            if (c0 == 0 && P.vec4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces
+            if (c0 == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and everything older)
+                if (tid == 0) {                                        // advance the ticket pipeline (see above)
+                    misc[2] = act_pend;
+                    act_pend = resolve(idx_pend);
+                    idx_pend = atomicAdd(P.ticket, 1);
+                }
+            }
             barrier_keep_vm();
             MF_STAMP(3)
             // pass 2: per voxel, frames in order: s *= a_f, k_f = g_f / s
@@ -653,7 +674,10 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                         const float a = 1.0f - P.iw * (S2 * rW);
                         o *= a; s *= a;
                         if (!(s >= RESCALE_BELOW)) {
+                            // fold s into the deltas, and into the k of this chunk's earlier frames
+                            // (their contributions are added in pass 3, in units of the old s)
                             for (int c = 0; c < C; ++c) D[v * C + c] *= s;
+                            for (int t = 0; t < j; ++t) reinterpret_cast<float *>(&W64[t * TV + v])[0] *= s;
                             s = 1.0f;
                         }
                         reinterpret_cast<float *>(&W64[j * TV + v])[0] = P.iw * rW * __builtin_amdgcn_rcpf(s);
@@ -664,10 +688,6 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             }
             __syncthreads();
             MF_STAMP(4)
-            if (c0 == 0) {
-                tile_next = misc[2];
-                if (tile_next >= 0) load_offs(tile_next, onext);      // in flight during pass 3
-            }
             // pass 3: D += k_f * w^2 * feat
             if (KIND == 0 || KIND == 1) {
                 auto add = [&](int e, const uint4 &r, uint32_t label) {
@@ -771,6 +791,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
         __syncthreads();
         MF_STAMP(6)
         tile = tile_next;
+        tile_next = misc[2];
         buf ^= 1;
     }
 }
@@ -882,7 +903,7 @@ static void choose_tile(const mf_grid *g, int n_groups, int &s0, int &s1, int &s
 static size_t tile_lds_fixed(int C, int sv)
 {
     const size_t TV = (size_t)1 << sv;
-    return TV * C * 4 + TV * 8 + 2 * (MAX_GROUPS + 1) * 4 + (MAX_CHUNK + 1) * 4 + 4 * 4 + MAX_GROUPS * 2 + TV + 16;
+    return TV * C * 4 + TV * 8 + 2 * (MAX_GROUPS + 1) * 4 + (MAX_CHUNK + 1) * 4 + 8 * 4 + MAX_GROUPS * 2 + TV + 16;
 }
 
 // frames per chunk: what fits next to the tile's deltas, at most 64 KB of accumulators
@@ -1076,7 +1097,17 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (stamps && nt > 256) kern = kind == 0 ? fuse_tiles_kernel<0, 1024, true> : kind == 1 ? fuse_tiles_kernel<1, 1024, true> : fuse_tiles_kernel<2, 1024, true>;
     if (stamps && nt <= 256 && nt > 64) kern = kind == 0 ? fuse_tiles_kernel<0, 256, true> : kind == 1 ? fuse_tiles_kernel<1, 256, true> : fuse_tiles_kernel<2, 256, true>;
     if (stamps) { unsigned long long z[8] = {}; MF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z))); }
-    MF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        // the dynamic-LDS limit of a kernel is raised once (per size): not a per-call cost
+        static std::mutex mu;
+        static std::unordered_map<const void *, size_t> granted;
+        std::lock_guard<std::mutex> lock(mu);
+        size_t &have = granted[(const void *)kern];
+        if (have < lds) {
+            MF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have = lds;
+        }
+    }
     TileParams T;
     T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = P.C; T.map = P.map; T.feat = P.feat;
     T.G = P.G; T.iw = P.iw; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2; T.nt1 = P.nt1; T.nt2 = P.nt2;
