@@ -284,7 +284,7 @@ def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
     rgb = BaseProjectionLayer(**dict(lay_kw, feature_size=3)).to(dev)
     d_dev, s_dev, c_dev = tr["depth"].to(dev), tr["semantic"].to(dev)[..., None], tr["rgb"].to(dev)
 
-    def run_traj(host_fed):
+    def run_traj(host_fed, validate=True):
         for lay in (occ, sem, rgb):
             lay.reset()
         torch.cuda.synchronize()
@@ -294,24 +294,29 @@ def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
                 o = dict(position=tr["position"][t].numpy(), yaw=float(tr["yaw"][t]), elevation=float(tr["elevation"][t]),
                          depth=d_np[t])
                 occ.update(o)
-                sem.update(dict(o, semantic=s_np[t]))
+                sem.update(dict(o, semantic=s_np[t]), validate=validate)
                 rgb.update(dict(o, features=c_np[t]))
             else:
                 o = dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t], depth=d_dev[t])
                 occ.update(o)
-                sem.update(dict(o, semantic=s_dev[t]))
+                sem.update(dict(o, semantic=s_dev[t]), validate=validate)
                 rgb.update(dict(o, features=c_dev[t]))
         torch.cuda.synchronize()
+        sem.check_labels()
         return time.perf_counter() - t0
     run_traj(False)
     dt = min(run_traj(False) for _ in range(2))
+    dt_defer = min(run_traj(False, validate="defer") for _ in range(2))
     d_np, s_np, c_np = tr["depth"].numpy(), tr["semantic"].numpy()[..., None].astype(np.int64), tr["rgb"].numpy()
     dt_host = run_traj(True)
     out["config3_trajectory_300x3maps"] = dict(
         frames_per_s=n3 / dt, ms_per_frame_3_maps=dt / n3 * 1e3, updates_per_s=3 * n3 / dt,
+        frames_per_s_deferred_label_check=n3 / dt_defer,
         host_fed_frames_per_s=n3 / dt_host, host_fed_ms_per_frame=dt_host / n3 * 1e3,
         note="per-frame layer.update() on occupancy (C=1), semantic (C=54 labels) and RGB (C=3 dense fp32) maps, "
-             "256^3 each, sequential; frames_per_s with observations resident in HBM, host_fed_* with numpy "
+             "256^3 each, sequential; frames_per_s with observations resident in HBM and the default class-id check "
+             "(update() waits for the semantic update to learn whether an id was out of range, as the reference's "
+             "one_hot does), frames_per_s_deferred_label_check with validate='defer' (no wait), host_fed_* with numpy "
              "observations uploaded per call (PCIe inclusive, int64 label image as the simulator produces it)")
     del occ, sem, rgb, d_dev, s_dev, c_dev
 

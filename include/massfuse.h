@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 1
+#define MF_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define MF_API __attribute__((visibility("default")))
@@ -86,6 +86,13 @@ typedef struct mf_frames {
     int32_t feat_height, feat_width;    /* resolution of `feat`; height%feat_height==0 etc.
                                            (repeat_interleave upsampling, base_projection_layer.py:322-325) */
     float min_depth, max_depth;         /* bin_rays min_ray_depth / max_ray_depth (0, 10)              */
+    int32_t *label_status;              /* optional (may be NULL), MF_FEAT_LABEL_* only: a device-visible
+                                           int32 (pinned host memory works) that is set to 1 when a valid
+                                           pixel carries a class id outside [0, channels); the call then
+                                           leaves the map untouched, like the reference, whose one_hot
+                                           raises before anything is written
+                                           (semantic_projection_layer.py:203-209).  With NULL such ids
+                                           count as an all-zero feature row.                             */
 } mf_frames;
 
 MF_API int mf_version(void);

@@ -20,7 +20,7 @@ FEAT_ONES, FEAT_LABEL_U8, FEAT_LABEL_I32, FEAT_LABEL_I64, FEAT_DENSE_F32 = 0, 1,
 MODE_SEQUENTIAL, MODE_MERGED = 0, 1
 METRIC_L2, METRIC_L2_GEMM, METRIC_COSINE = 0, 1, 2
 MAX_FRAMES_PER_CALL = 256
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_float, ctypes.c_size_t)
@@ -37,7 +37,7 @@ class MfFrames(ctypes.Structure):
     _fields_ = [("n_frames", c_int32), ("height", c_int32), ("width", c_int32),
                 ("cam_rays", c_void_p), ("poses", c_void_p), ("depth", c_void_p), ("feat", c_void_p),
                 ("feat_kind", c_int32), ("feat_height", c_int32), ("feat_width", c_int32),
-                ("min_depth", c_float), ("max_depth", c_float)]
+                ("min_depth", c_float), ("max_depth", c_float), ("label_status", c_void_p)]
 
 
 # every symbol include/massfuse.h declares: name -> (restype, argtypes)

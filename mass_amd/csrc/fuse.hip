@@ -55,6 +55,7 @@ struct FuseParams {
     const void *feat;
     int feat_kind, fh, fw, rep_y, rep_x;
     float min_d, max_d;
+    int *label_status;         // optional: set to 1 (and the call aborted) on a class id outside [0, C)
     // binned points (front end 1)
     const int64_t *i0, *i1, *i2;
     const float *q0, *q1, *q2;
@@ -190,6 +191,8 @@ __device__ __forceinline__ int point_keys(const FuseParams &P, const Point &pt, 
 // ----------------------------------------------------------------------------
 // per-block LDS hash: bucket key -> (count, base)
 // ----------------------------------------------------------------------------
+constexpr int TILE_CLASSES = 4;          // load classes of the tile work list (tile_list_kernel)
+constexpr int ABORT_SLOT = 1 + TILE_CLASSES;   // ticket[ABORT_SLOT] != 0: a class id was out of range, the call is called off
 constexpr int BIN_THREADS = 256;
 constexpr int HS_BITS = 8;
 constexpr int HS = 1 << HS_BITS;
@@ -217,6 +220,10 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
     if (idx >= 0) {
         Point pt; uint32_t aux = 0;
         if (get_point<FRONT>(P, idx, pt, aux)) {
+            if (P.label_status && P.feat_kind >= MF_FEAT_LABEL_U8 && P.feat_kind <= MF_FEAT_LABEL_I64 && aux >= (uint32_t)P.C) {
+                *P.label_status = 1;                    // reported to the host ...
+                P.ticket[ABORT_SLOT] = 1;               // ... and the rest of the pipeline is called off
+            }
             uint32_t keys[8];
             const int n = point_keys(P, pt, keys);
             for (int i = 0; i < n; ++i) {
@@ -320,7 +327,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int *data, int
 // ticket[0] = work counter of the tile kernel, ticket[1 + c] = tiles in class c.
 // Class 0 holds the tiles with the most entries; the tile kernel walks class 0,
 // 1, 2, 3 in that order so the long tiles start first and the tail is short.
-constexpr int TILE_CLASSES = 4;
 
 __device__ __forceinline__ int tile_class(int n)
 {
@@ -332,6 +338,7 @@ __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ 
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     int n = 0;
+    if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
     if (t < n_tiles) n = cursor[(t + 1) * G] - cursor[t * G];
     const int cls = tile_class(n);
     const int lane = threadIdx.x & 63;
@@ -1009,6 +1016,7 @@ static void fill_frames(FuseParams &P, const mf_frames *f)
     P.fw = f->feat_kind == MF_FEAT_ONES ? f->width : f->feat_width;
     P.rep_y = f->height / P.fh; P.rep_x = f->width / P.fw;
     P.min_d = f->min_depth; P.max_d = f->max_depth;
+    P.label_status = f->label_status;
     P.n_points = (long long)f->n_frames * f->height * f->width;
 }
 

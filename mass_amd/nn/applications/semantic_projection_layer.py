@@ -60,7 +60,7 @@ class SemanticProjectionLayer(BaseProjectionLayer):
         super(SemanticProjectionLayer, self).reset(
             origin_y=origin_y, origin_x=origin_x, origin_z=origin_z)
 
-    def _labels(self, semantic, validate):
+    def _labels(self, semantic):
         """Class-id image for the kernel: [H, W] (or [B, H, W]) uint8 / int32 / int64 on the
         device.  Host arrays are uploaded as they are (an int64 480x640 image is 2.4 MB and takes
         ~60 us; narrowing it on the host first costs far more than it saves)."""
@@ -72,26 +72,48 @@ class SemanticProjectionLayer(BaseProjectionLayer):
         semantic = semantic.to(device=self.data.device)
         if semantic.dtype not in (torch.uint8, torch.int32, torch.int64):
             semantic = semantic.to(torch.int64)
-        if validate and semantic.numel() and (int(semantic.min()) < 0 or
-                                              int(semantic.max()) >= self.feature_size):
-            # functional.one_hot in the reference raises for these
-            raise RuntimeError("Class values must be non-negative and smaller than num_classes.")
         return semantic
 
-    def update(self, observation: Dict[str, torch.Tensor], validate: bool = False):
-        """semantic_projection_layer.py:165-216.  validate=True adds the range
-        check one_hot performs (costs a device sync); ids outside [0, C) are
-        otherwise splatted as an all-zero feature row."""
+    _CLASS_ERROR = "Class values must be non-negative and smaller than num_classes."
+
+    def _status(self):
+        """Pinned host word the kernels raise when a class id is outside [0, C)."""
+        if getattr(self, "_label_status", None) is None:
+            self._label_status = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._label_status
+
+    def check_labels(self, synchronize: bool = True):
+        """Raise if an update since the last check met a class id outside [0, feature_size)
+        (such an update left the map untouched).  validate="defer" updates rely on this."""
+        st = getattr(self, "_label_status", None)
+        if st is None:
+            return
+        if synchronize:
+            torch.cuda.current_stream(self.data.device).synchronize()
+        if int(st[0]) != 0:
+            st[0] = 0
+            raise RuntimeError(self._CLASS_ERROR)
+
+    def _update(self, observation, sequential, validate):
+        if validate == "defer":
+            self.check_labels(synchronize=False)         # whatever an earlier update has reported by now
         self._splat(observation["position"], observation["yaw"], observation["elevation"],
-                    observation["depth"], self._labels(observation["semantic"], validate))
+                    observation["depth"], self._labels(observation["semantic"]), sequential=sequential,
+                    label_status=self._status() if validate else None)
+        if validate is True:
+            self.check_labels(synchronize=True)
         return self
 
-    def update_batch(self, observation: Dict[str, torch.Tensor], sequential: bool = True,
-                     validate: bool = False):
-        self._splat(observation["position"], observation["yaw"], observation["elevation"],
-                    observation["depth"], self._labels(observation["semantic"], validate),
-                    sequential=sequential)
-        return self
+    def update(self, observation: Dict[str, torch.Tensor], validate=True):
+        """semantic_projection_layer.py:165-216.  Class ids outside [0, feature_size) raise like the
+        reference's one_hot (:203-209) and leave the map untouched: the kernels detect them and call
+        the update off; validate=True (default) waits for the update to learn that, "defer" reports
+        it at the next update / check_labels() instead (no wait), False skips the check (such ids
+        then count as an all-zero feature row)."""
+        return self._update(observation, True, validate)
+
+    def update_batch(self, observation: Dict[str, torch.Tensor], sequential: bool = True, validate=True):
+        return self._update(observation, sequential, validate)
 
     # ------------------------------------------------------------------ find
     def _voxel_centres(self):

@@ -18,6 +18,9 @@ from mass_amd.utils.projection import (project_camera_rays, spherical_to_cartesi
                                        fuse_frames, Workspace)
 
 
+_POSE_CACHE = {}      # last single-frame pose: {"key": (device, x, y, z, yaw, elevation), "pose": device tensor}
+
+
 def _edges(origin, cells, resolution):
     """cells + 1 bin edges centred on origin (base_projection_layer.py:164-181).
     The values are whatever torch.arange produces on the host; they are data."""
@@ -82,21 +85,34 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         """Host-side pose math with the reference's torch ops on the CPU
         (projection.py:29-31,104-105; base_projection_layer.py:330-331), so the
         device never evaluates sin/cos and the rotation is bit-identical to the
-        reference CPU path.  Returns device [B, 12]."""
+        reference CPU path.  Returns device [B, 12].
+
+        agent.py updates several maps with the same observation per simulator step
+        (navigation_policy.py:167-171): the packed pose of the last single-frame call is
+        kept (per device) and reused when position / yaw / elevation are the same."""
         position = torch.as_tensor(position, dtype=torch.float32, device='cpu').reshape(-1, 3)
         yaw = torch.as_tensor(yaw, dtype=torch.float32, device='cpu').reshape(-1)
         elevation = torch.as_tensor(elevation, dtype=torch.float32, device='cpu').reshape(-1)
+        key = None
+        if position.shape[0] == 1:
+            key = (self.data.device, *position[0].tolist(), float(yaw[0]), float(elevation[0]))
+            hit = _POSE_CACHE.get("key") == key
+            if hit:
+                return _POSE_CACHE["pose"]
         eye = spherical_to_cartesian(yaw, elevation)
         up = spherical_to_cartesian(yaw, elevation + np.pi / 2)
-        return pack_poses(position, eye, up).to(self.data.device, non_blocking=True)
+        pose = pack_poses(position, eye, up).to(self.data.device, non_blocking=True)
+        if key is not None:
+            _POSE_CACHE["key"], _POSE_CACHE["pose"] = key, pose
+        return pose
 
-    def _splat(self, position, yaw, elevation, depth, features, sequential=True):
+    def _splat(self, position, yaw, elevation, depth, features, sequential=True, label_status=None):
         depth = torch.as_tensor(depth, dtype=torch.float32, device=self.data.device)
         self._map_version += 1
         fuse_frames(self.bins_x, self.bins_y, self.bins_z, self.rays,
                     self._poses(position, yaw, elevation), depth, features, self.data,
                     interpolation_weight=self.interpolation_weight, sequential=sequential,
-                    workspace=self._workspace)
+                    workspace=self._workspace, label_status=label_status)
 
     def update(self, observation: Dict[str, torch.Tensor]):
         """Project one posed depth + feature frame onto the map, in place

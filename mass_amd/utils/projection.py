@@ -208,14 +208,17 @@ def update_feature_map(ind0, ind1, ind2, ratio0, ratio1, ratio2,
 
 def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map,
                 interpolation_weight=0.5, sequential=True, min_ray_depth=0.0, max_ray_depth=10.0,
-                workspace=None):
+                workspace=None, label_status=None):
     """transform_rays + bin_rays + update_feature_map for a batch of posed
     frames in one fused pipeline (what BaseProjectionLayer.update runs).
 
     cam_rays [H, W, 3]; poses [B, 12] (pack_poses); depth [B, H, W(, 1)];
     features: None (ones, C == 1), integer class ids [B, h, w] or fp32
     [B, h, w, C] with h | H and w | W.  sequential=True reproduces B successive
-    layer.update() calls, False the functional API's merged batch."""
+    layer.update() calls, False the functional API's merged batch.
+
+    label_status: optional pinned-host (or device) int32 tensor; the kernels set it to 1 and leave
+    the map untouched when a valid pixel carries a class id outside [0, C) (mf_frames.label_status)."""
     fm = _check_map(feature_map)
     require_device(bins_x, bins_y, bins_z, cam_rays, poses, depth, features)
     H, W = cam_rays.shape[0], cam_rays.shape[1]
@@ -232,6 +235,7 @@ def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, featur
     fr.cam_rays = cam.data_ptr()
     fr.min_depth, fr.max_depth = float(min_ray_depth), float(max_ray_depth)
     fr.feat_kind = kind
+    fr.label_status = label_status.data_ptr() if label_status is not None else None
     if kind == _lib.FEAT_DENSE_F32:
         feat = feat.reshape(B, -1, feat.shape[-2], C) if feat.dim() >= 3 else feat
         fr.feat_height, fr.feat_width = feat.shape[1], feat.shape[2]

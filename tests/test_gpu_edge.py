@@ -140,3 +140,20 @@ def test_stage_timing_diagnostics(device):
     _lib.check(_lib.lib.mf_profile_enable(0))
     lay.update({k: v[3] for k, v in fr.items() if k != "semantic"})
     assert _lib.lib.mf_profile_read(3, ms.ctypes.data) < 0          # not recorded while disabled
+
+
+@pytest.mark.parametrize("kind", ["label", "ones"])
+def test_long_sequence_folds_the_lazy_decay_mid_chunk(device, kind):
+    """200 near-identical frames with interpolation_weight 1: the per-voxel decay product drops
+    below 2^-40 every ~50 frames, so it is folded into the LDS deltas while earlier frames of the
+    same chunk still have contributions pending (they must be rescaled with it)."""
+    n, h, w, C = 200, 12, 16, 6
+    g = torch.Generator().manual_seed(5)
+    depth = (0.6 + 0.5 * torch.rand(1, h, w, 1, generator=g)).expand(n, h, w, 1).clone()
+    depth += 1e-3 * torch.rand(n, h, w, 1, generator=g)                 # same voxels, slightly different weights
+    fr = dict(position=torch.zeros(n, 3), yaw=torch.full((n,), 0.4), elevation=torch.full((n,), -0.3), depth=depth,
+              semantic=torch.randint(0, C, (1, h, w), generator=g).expand(n, h, w).clone())
+    kw = dict(camera_height=h, camera_width=w, map_height=16, map_width=16, map_depth=16, feature_size=C if kind == "label" else 1,
+              grid_resolution=0.15)
+    lay, ol = run_pair(kw, fr, device, kind=kind, iw=1.0)
+    assert float(ol.data.max()) > 0.1

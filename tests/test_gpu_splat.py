@@ -213,3 +213,44 @@ def test_resnet_layer_splat_at_quarter_resolution(device):
         lay.update(dict(pose, depth=depth, rgb=rgb))
         ol.update(dict(pose, depth=torch.tensor(depth)[2::4, 2::4], features=extractor(rgb)))
     assert_map_close(lay.data.cpu().numpy(), ol.data.numpy())
+
+
+def test_out_of_range_class_ids_raise_and_leave_the_map_untouched(device):
+    """The reference's one_hot raises on a class id outside [0, C) before anything is written
+    (semantic_projection_layer.py:203-209): so does update() by default, with the map untouched;
+    validate="defer" reports at the next call; validate=False counts such ids as zero rows."""
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    from oracle import massref as orc
+    H, W, C, M = SMALL["H"], SMALL["W"], 5, SMALL["MAP"]
+    kw = dict(camera_height=H, camera_width=W, map_height=M, map_width=M, map_depth=M, feature_size=C,
+              grid_resolution=SMALL["RES"])
+    g = torch.Generator().manual_seed(1)
+    depth = 0.5 + 1.5 * torch.rand(H, W, 1, generator=g)
+    good = torch.randint(0, C, (H, W, 1), generator=g)
+    obs = dict(position=np.zeros(3, np.float32), yaw=0.3, elevation=-0.4, depth=depth)
+    lay = SemanticProjectionLayer(**kw).to(device)
+    lay.update(dict(obs, semantic=good))
+    before = lay.data.clone()
+    for bad_value, dtype in ((C, torch.int64), (-1, torch.int64), (200, torch.uint8), (C + 7, torch.int32)):
+        bad = good.clone().to(dtype)
+        bad[H // 2, W // 2, 0] = bad_value
+        with pytest.raises(RuntimeError, match="Class values"):
+            lay.update(dict(obs, semantic=bad))
+        assert torch.equal(lay.data, before)                      # the update was called off as a whole
+    lay.update(dict(obs, semantic=good))                           # and the layer keeps working
+    assert not torch.equal(lay.data, before)
+    # deferred: reported by the next call (or check_labels), map untouched by the bad frame
+    mid = lay.data.clone()
+    bad = good.clone(); bad[0, 0, 0] = C
+    lay.update(dict(obs, semantic=bad), validate="defer")
+    with pytest.raises(RuntimeError, match="Class values"):
+        lay.check_labels()
+    assert torch.equal(lay.data, mid)
+    # unchecked: the id stands for an all-zero feature row (still decays what it lands on)
+    ref = orc.RefProjectionLayer(**kw)
+    ref.data.copy_(mid.cpu())
+    onehot = torch.nn.functional.one_hot(good[..., 0], C + 1).float()
+    onehot_bad = torch.nn.functional.one_hot(bad[..., 0], C + 1).float()[..., :C]
+    ref.update(dict(obs, features=onehot_bad))
+    lay.update(dict(obs, semantic=bad), validate=False)
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="unchecked ids")
