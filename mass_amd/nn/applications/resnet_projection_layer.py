@@ -1,15 +1,15 @@
 """ResNetProjectionLayer — dense image features splatted at 1/4 camera resolution.
 
-Mirrors /root/reference/mass/nn/applications/resnet_projection_layer.py for the part that is
-on the hot path: the layer is built at camera_height // 4 x camera_width // 4 (:120-131) and
-``update`` splats a [h, w, C] fp32 feature image with the depth sampled at the centre of each
+Mirrors /root/reference/mass/nn/applications/resnet_projection_layer.py: the layer is built at
+camera_height // 4 x camera_width // 4 (:120-131); ``update`` runs the ResNet-50 stem + layer1 on
+the RGB frame (``pseudo_forward``, :143-157; here mass_amd.nn.models.resnet_stem, torch / MIOpen)
+and splats the [h, w, 256] fp32 feature image with the depth sampled at the centre of each
 feature pixel, ``depth[f // 2::f, f // 2::f]`` (:201-211), through the HIP pipeline.
 
-The feature extractor itself (ResNet-50 stem + layer1 on the RGB frame, :143-157) is out of
-scope (its weights are a remote download, and convolution belongs to MIOpen):
-pass any callable ``feature_extractor(rgb [H, W, 3] in [0, 1]) -> [h, w, C]`` tensor.  Without
-one the layer tries torchvision's resnet50 with locally available weights and fails loudly if
-that is not possible.
+The reference downloads pretrained weights (``resnet50(pretrained=True)``, :134): offline that is
+impossible, so the default extractor keeps a seeded random initialisation unless ``weights`` names
+a local torchvision resnet50 checkpoint.  Any callable ``feature_extractor(rgb) -> [h, w, C]``
+can be plugged in instead.
 """
 from typing import Callable, Dict, Optional
 
@@ -17,27 +17,7 @@ import numpy as np
 import torch
 
 from mass_amd.nn.base_projection_layer import BaseProjectionLayer
-
-
-def _torchvision_layer1(device):
-    try:
-        from torchvision.models import resnet50
-    except Exception as exc:                      # torchvision is not in this image
-        raise ImportError("ResNetProjectionLayer needs a feature_extractor (torchvision is not "
-                          "installed, and the reference's pretrained weights are a remote download)") from exc
-    model = resnet50(weights=None).eval().to(device)
-    mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
-    std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
-
-    def extract(rgb):
-        x = torch.as_tensor(rgb, dtype=torch.float32, device=device).permute(2, 0, 1).unsqueeze(0)
-        scale = 224.0 / min(x.shape[-2:])
-        x = torch.nn.functional.interpolate(x, scale_factor=scale, mode="bilinear", antialias=True)
-        x = (x - mean) / std
-        with torch.no_grad():
-            x = model.layer1(model.maxpool(model.relu(model.bn1(model.conv1(x)))))
-        return x.squeeze(0).permute(1, 2, 0)
-    return extract
+from mass_amd.nn.models.resnet_stem import ResNetFeatureExtractor
 
 
 class ResNetProjectionLayer(BaseProjectionLayer):
@@ -50,7 +30,8 @@ class ResNetProjectionLayer(BaseProjectionLayer):
                  origin_z: float = 0.0, grid_resolution: float = 0.05,
                  interpolation_weight: float = 0.5,
                  initial_feature_map: torch.Tensor = None,
-                 feature_extractor: Optional[Callable] = None):
+                 feature_extractor: Optional[Callable] = None,
+                 weights: Optional[str] = None):
         super(ResNetProjectionLayer, self).__init__(
             camera_height=camera_height // 4, camera_width=camera_width // 4,
             vertical_fov=vertical_fov, map_height=map_height,
@@ -61,6 +42,13 @@ class ResNetProjectionLayer(BaseProjectionLayer):
             interpolation_weight=interpolation_weight,
             initial_feature_map=initial_feature_map)
         self.feature_extractor = feature_extractor
+        self.weights = weights
+
+    def pseudo_forward(self, x):
+        """resnet_projection_layer.py:143-157 on an already normalised [N, 3, H, W] batch."""
+        if self.feature_extractor is None:
+            self.feature_extractor = ResNetFeatureExtractor(self.data.device, weights=self.weights)
+        return self.feature_extractor.model(x.to(self.data.device))
 
     def update(self, observation: Dict[str, torch.Tensor]):
         """resnet_projection_layer.py:159-213.  Keys: position, yaw, elevation, depth [H, W, 1],
@@ -70,7 +58,7 @@ class ResNetProjectionLayer(BaseProjectionLayer):
             features = torch.as_tensor(observation["features"], dtype=torch.float32, device=self.data.device)
         else:
             if self.feature_extractor is None:
-                self.feature_extractor = _torchvision_layer1(self.data.device)
+                self.feature_extractor = ResNetFeatureExtractor(self.data.device, weights=self.weights)
             features = torch.as_tensor(self.feature_extractor(observation["rgb"]), dtype=torch.float32,
                                        device=self.data.device)
         f = depth.shape[0] // features.shape[0]               # image_downsampling_factor (:201)
