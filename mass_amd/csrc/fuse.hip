@@ -130,7 +130,9 @@ __device__ __forceinline__ bool get_point(const FuseParams &P, long long idx, Po
         const bool ok = bin_point(P.bins, p0, p1, p2, d, P.min_d, P.max_d, kx, ky, kz, rx, ry, rz);
         pt.k0 = ky; pt.k1 = kx; pt.k2 = kz; pt.r0 = ry; pt.r1 = rx; pt.r2 = rz;
         pt.group = P.G == 1 ? 0 : f;
-        if (ok && P.feat_kind != MF_FEAT_ONES) {
+        // the class id is also read for pixels that miss the map when ids are being checked: the
+        // reference's one_hot looks at every pixel (semantic_projection_layer.py:203-209)
+        if ((ok || P.label_status) && P.feat_kind != MF_FEAT_ONES) {
             const int y = pix / P.W, x = pix - y * P.W;
             const long long fi = ((long long)f * P.fh + y / P.rep_y) * P.fw + x / P.rep_x;
             aux = P.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)fi : read_label(P.feat, P.feat_kind, fi);
@@ -219,11 +221,12 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
     const long long idx = point_index<FRONT>(P, BIN_THREADS);
     if (idx >= 0) {
         Point pt; uint32_t aux = 0;
-        if (get_point<FRONT>(P, idx, pt, aux)) {
-            if (P.label_status && P.feat_kind >= MF_FEAT_LABEL_U8 && P.feat_kind <= MF_FEAT_LABEL_I64 && aux >= (uint32_t)P.C) {
-                *P.label_status = 1;                    // reported to the host ...
-                P.ticket[ABORT_SLOT] = 1;               // ... and the rest of the pipeline is called off
-            }
+        const bool ok = get_point<FRONT>(P, idx, pt, aux);
+        if (P.label_status && P.feat_kind >= MF_FEAT_LABEL_U8 && P.feat_kind <= MF_FEAT_LABEL_I64 && aux >= (uint32_t)P.C) {
+            *P.label_status = 1;                        // reported to the host ...
+            P.ticket[ABORT_SLOT] = 1;                   // ... and the rest of the pipeline is called off
+        }
+        if (ok) {
             uint32_t keys[8];
             const int n = point_keys(P, pt, keys);
             for (int i = 0; i < n; ++i) {
@@ -333,13 +336,32 @@ __device__ __forceinline__ int tile_class(int n)
     return n >= 8192 ? 0 : n >= 2048 ? 1 : n >= 512 ? 2 : 3;
 }
 
+// Work items of fuse_single_kernel (single-group calls with class-id / ones features, split_min > 0):
+// every non-empty tile, a tile with more than split_min records cut into `nparts` record ranges.
+constexpr int SPLIT_ITEMS = ABORT_SLOT + 1, SPLIT_TILES = ABORT_SLOT + 2;
+constexpr int SPLIT_PARTS_MAX = 64;
+
 __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
-                                                        int n_tiles, int G, int *ticket, int *active)
+                                                        int n_tiles, int G, int *ticket, int *active,
+                                                        int split_min, int split_part, int split_slots, int *items)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     int n = 0;
     if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
     if (t < n_tiles) n = cursor[(t + 1) * G] - cursor[t * G];
+    if (split_min > 0 && n > 0) {                   // single-pass kernel: every tile is an item, big ones in parts
+        int nparts = 1, slot = 0xffff;
+        if (n > split_min) {
+            slot = atomicAdd(&ticket[SPLIT_TILES], 1);
+            if (slot < split_slots) {
+                nparts = (n + split_part - 1) / split_part;
+                if (nparts > SPLIT_PARTS_MAX) nparts = SPLIT_PARTS_MAX;
+            } else slot = 0xffff;                   // out of scratch slots: stays whole
+        }
+        const int base = atomicAdd(&ticket[SPLIT_ITEMS], nparts);
+        for (int p = 0; p < nparts; ++p) { items[2 * (base + p)] = t; items[2 * (base + p) + 1] = p | (nparts << 8) | (slot << 16); }
+        return;                                     // nothing is listed for the tile kernel
+    }
     const int cls = tile_class(n);
     const int lane = threadIdx.x & 63;
     for (int c = 0; c < TILE_CLASSES; ++c) {
@@ -804,6 +826,211 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 }
 
 // ----------------------------------------------------------------------------
+// single-group calls with class-id / ones features: one pass, integer sums
+// ----------------------------------------------------------------------------
+// With one group (a frame, or a merged batch) the update of a voxel is
+//     new = a * old + g * U,   a = 1 - iw*S2/W,  g = iw/W,  U[c] = sum of w^2 over the corners with class c,
+// and W, S2, U are plain sums over the records: no frame order, no scale to carry, nothing to read
+// before the end.  So the tile's records are expanded ONCE and W, S2 and U are all accumulated as
+// 64-bit fixed-point LDS integer atomics.  That is what a real scene needs: its neighbouring
+// pixels land on the same voxel with the same class (28-136 points per voxel), and LDS float
+// adds by compare-and-swap collapse there (lost races fall back to ds_add_f32, 29x slower than
+// the integer atomic), while integer atomics on one word just queue up; the sums are exact and
+// run-to-run identical as well.  A work item is a tile or, for a tile with many records, one of
+// `nparts` record ranges: parts add what they touched to the tile's scratch slot in global memory
+// (integer atomics: performed at the memory side, coherent across XCDs) and the part that arrives
+// last reads the totals back and applies them.  Items are dealt round-robin (no ticket, no
+// dependent look-ups): parts are bounded in size, so static dealing balances.
+//   ticket[SPLIT_ITEMS] = items listed, ticket[SPLIT_TILES] = scratch slots handed out;
+//   item = {tile, part | nparts << 8 | slot << 16}; the scratch is zeroed by the call's memset.
+struct SingleParams {
+    int size0, size1, size2, C;
+    float *map;
+    float iw;
+    int s0, s1, s2;
+    int nt1, nt2;
+    unsigned magicC;
+    int fx_shift;
+    const int *cursor;
+    const int *ticket;
+    const int *items;
+    const uint4 *rec;
+    const uint32_t *aux;
+    int *slot_count;                   // [slots] parts arrived
+    unsigned long long *slot_ws;       // [slots][TV][2] W, S2
+    unsigned long long *slot_u;        // [slots][TV * C] U (labels only; ones: U = S2)
+    unsigned *slot_bits;               // [slots][ceil(TV * C / 32)] (voxel, class) pairs that met a sub-unit corner
+};
+
+template <int KIND, int NT>
+__global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
+{
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x;
+    const int C = P.C;
+    const int sv = P.s0 + P.s1 + P.s2;
+    const int TV = 1 << sv;
+    const unsigned n_el = (unsigned)TV * (unsigned)C;
+    unsigned long long *U64 = reinterpret_cast<unsigned long long *>(smem);     // [TV][C] (labels)
+    unsigned long long *W64 = U64 + (KIND == 1 ? n_el : 0);                      // [TV]
+    unsigned long long *S64 = W64 + TV;                                          // [TV]
+    unsigned long long *T64 = S64 + TV;                                          // [TV] sum of the sub-unit w^2, 34 more fraction bits
+    float *sa = reinterpret_cast<float *>(T64 + TV);                             // [TV] a
+    float *sg = sa + TV;                                                         // [TV] g (times 2^-shift), 0 = untouched
+    float *st = sg + TV;                                                         // [TV] value added to a class that only met sub-unit corners
+    int *misc = reinterpret_cast<int *>(st + TV);
+    unsigned *bits = reinterpret_cast<unsigned *>(misc + 4);                     // [ceil(n_el / 32)] (labels)
+    const int n_bits = KIND == 1 ? (int)((n_el + 31) >> 5) : 0;
+    const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
+    const int fx_c = 182 - P.fx_shift;
+    const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);
+    // Fixed point has an absolute resolution (one unit = 2^-shift): a corner weight below
+    // sqrt(unit) ~ 3e-7 (a point on a voxel boundary has 1e-9) squares to less than a unit.  Such
+    // squares go to a second per-voxel sum with 34 more fraction bits (they are below 2^-shift each,
+    // so the sum of all of a call's points still fits), which completes S2, and the (voxel, class)
+    // pairs they belong to are remembered in a bitmap: a class that received nothing else gets the
+    // voxel's sub-unit sum, split evenly if several classes share it (exact for the usual single
+    // corner; the shares are below 2e-7 in any case).
+    const int fx_c2 = fx_c - 34;
+    const float fx_inv2 = fx_inv * 5.8207661e-11f;                               // 2^-34
+    // for_corners wants the tile kernel's parameter block: only the geometry fields are read
+    TileParams T;
+    T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = C; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2;
+    const int n_items = P.ticket[SPLIT_ITEMS];
+
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int tile = P.items[2 * it], meta = P.items[2 * it + 1];
+        const int part = meta & 255, nparts = (meta >> 8) & 255, slot = (meta >> 16) & 0xffff;
+        const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
+        const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
+        const int s = tile > 0 ? P.cursor[tile - 1] : 0, e = P.cursor[tile];      // one group: bucket key = tile
+        const int len = (e - s + nparts - 1) / nparts;
+        const int ea = s + part * len, eb = min(e, ea + len);
+        if (KIND == 1) {
+            uint4 *z = reinterpret_cast<uint4 *>(U64);
+            for (unsigned i = tid; i < (n_el >> 1); i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+            if ((n_el & 1) && tid == 0) U64[n_el - 1] = 0ull;
+        }
+        for (int v = tid; v < TV; v += NT) { W64[v] = 0ull; S64[v] = 0ull; T64[v] = 0ull; }
+        for (int k = tid; k < n_bits; k += NT) bits[k] = 0u;
+        __syncthreads();
+        for (int q = ea + tid; q < eb; q += NT) {
+            const uint4 r = P.rec[q];
+            const uint32_t label = KIND == 1 ? P.aux[q] : 0u;
+            for_corners(T, r, o0, o1, o2, [&](int v, float w) {
+                const unsigned long long w2 = to_fixed(w * w, fx_c);
+                atomicAdd(&W64[v], to_fixed(w, fx_c));
+                if (w2 != 0ull) atomicAdd(&S64[v], w2);
+                else atomicAdd(&T64[v], to_fixed(w * w, fx_c2));
+                if (KIND == 1 && label < (uint32_t)C) {
+                    const unsigned i = (unsigned)v * C + label;
+                    if (w2 != 0ull) atomicAdd(&U64[i], w2);
+                    else atomicOr(&bits[i >> 5], 1u << (i & 31));
+                }
+            });
+        }
+        __syncthreads();
+        bool finish = true;
+        unsigned long long *ws = nullptr, *us = nullptr;
+        if (nparts > 1) {
+            // this part's sums -> the tile's slot; the last part to arrive takes the totals back
+            ws = P.slot_ws + ((size_t)slot * TV) * 3;
+            us = P.slot_u + (size_t)slot * n_el;
+            for (int v = tid; v < TV; v += NT)
+                if (W64[v] != 0ull) {
+                    atomicAdd(&ws[3 * v], W64[v]);
+                    if (S64[v] != 0ull) atomicAdd(&ws[3 * v + 1], S64[v]);
+                    if (T64[v] != 0ull) atomicAdd(&ws[3 * v + 2], T64[v]);
+                }
+            unsigned *bs = P.slot_bits + (size_t)slot * n_bits;
+            if (KIND == 1) {
+                for (unsigned i = tid; i < n_el; i += NT)
+                    if (U64[i] != 0ull) atomicAdd(&us[i], U64[i]);
+                for (int k = tid; k < n_bits; k += NT)
+                    if (bits[k] != 0u) atomicOr(&bs[k], bits[k]);
+            }
+            __threadfence();                               // the adds above are performed before the arrival below
+            __syncthreads();
+            if (tid == 0) misc[1] = atomicAdd(&P.slot_count[slot], 1) == nparts - 1;
+            __syncthreads();
+            finish = misc[1] != 0;
+            if (finish) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                for (int v = tid; v < TV; v += NT) {       // totals through the atomic path
+                    W64[v] = atomicAdd(&ws[3 * v], 0ull);
+                    S64[v] = atomicAdd(&ws[3 * v + 1], 0ull);
+                    T64[v] = atomicAdd(&ws[3 * v + 2], 0ull);
+                }
+                for (int k = tid; k < n_bits; k += NT) bits[k] = atomicOr(&bs[k], 0u);
+                __syncthreads();
+            }
+        }
+        if (finish) {
+            // per voxel: a, the factor that turns the integer U[c] into the added value g * U[c], and
+            // what a class that only met sub-unit corners gets
+            for (int v = tid; v < TV; v += NT) {
+                const unsigned long long wq = W64[v];
+                float a = 1.0f, g = 0.0f, t = 0.0f;
+                if (wq != 0ull) {
+                    const float Wv = (float)wq * fx_inv;
+                    const unsigned long long sq = S64[v], tq = T64[v];
+                    const float tiny = (float)tq * fx_inv2;
+                    const float S2 = (float)sq * fx_inv + tiny;
+                    const float rW = __builtin_amdgcn_rcpf(Wv);
+                    a = 1.0f - P.iw * (S2 * rW);
+                    g = P.iw * rW * fx_inv;                                    // times U in units
+                    if (KIND == 0) g = P.iw * rW * S2;                         // features = ones: U = S2
+                    else if (tq != 0ull) {
+                        int flagged = 0;
+                        for (int c = 0; c < C; ++c) {
+                            const unsigned i = (unsigned)v * C + c;
+                            flagged += (bits[i >> 5] >> (i & 31)) & 1u;
+                        }
+                        t = flagged ? P.iw * rW * tiny / (float)flagged : 0.0f;
+                    }
+                }
+                sa[v] = a; sg[v] = g; st[v] = t;
+            }
+            __syncthreads();
+            // read-modify-write of the touched voxels, FB elements per thread at a time with all their
+            // loads in flight before the first use (the loop is otherwise one HBM latency per element)
+            constexpr int FB = 8;
+            for (unsigned b0 = 0; b0 < n_el; b0 += NT * FB) {
+                float old[FB], add[FB], av[FB];
+                size_t gi[FB];
+                bool on[FB];
+#pragma unroll
+                for (int j = 0; j < FB; ++j) {
+                    const unsigned i = b0 + j * NT + tid;
+                    on[j] = false;
+                    if (i < n_el) {
+                        const unsigned v = KIND == 0 ? i : div_magic(i, P.magicC);
+                        const float g = sg[v];
+                        if (g != 0.0f) {
+                            const unsigned c = i - v * C;
+                            const int l2 = v & m2, l1 = (v >> P.s2) & m1, l0 = v >> (P.s1 + P.s2);
+                            gi[j] = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2)) * C + c;
+                            old[j] = P.map[gi[j]];
+                            add[j] = g;
+                            if (KIND == 1) {
+                                const unsigned long long u = nparts > 1 ? atomicAdd(&us[i], 0ull) : U64[i];
+                                add[j] = g * (float)u + ((bits[i >> 5] >> (i & 31)) & 1u ? st[v] : 0.0f);
+                            }
+                            av[j] = sa[v];
+                            on[j] = true;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FB; ++j)
+                    if (on[j]) P.map[gi[j]] = av[j] * old[j] + add[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------
 // parity kernels (a3, a4, fused a3+a4)
 // ----------------------------------------------------------------------------
 __global__ void transform_rays_kernel(const float *__restrict__ cam, long long n_pix,
@@ -934,10 +1161,20 @@ static size_t tile_lds_bytes(int C, int sv, int gc)
 }
 
 struct Layout {
-    size_t cursor, block_sums, ticket, active, rec, aux, total;
+    size_t cursor, block_sums, ticket, slot_count, slot_ws, slot_u, slot_bits, active, items, rec, aux, total;
     int n_keys, n_scan_blocks;
+    int split_slots, split_items;      // 0: no split tiles (sequential groups, or MF_SPLIT=0)
     long long cap;
 };
+
+constexpr int SPLIT_MIN = 1536;        // a tile with more records (single group) is cut into parts ...
+constexpr int SPLIT_PART = 1024;       // ... of about this many records
+
+static bool split_enabled()
+{
+    static const bool on = !(getenv("MF_SPLIT") && atoi(getenv("MF_SPLIT")) == 0);
+    return on;
+}
 
 static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int s1, int s2, Layout &L,
                         int &nt0, int &nt1, int &nt2)
@@ -955,7 +1192,23 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
     L.cursor = off; off = align_up(off + (size_t)(n_keys + 1) * 4, 256);
     L.block_sums = off; off = align_up(off + (size_t)L.n_scan_blocks * 4, 256);
     L.ticket = off; off = align_up(off + 256, 256);
+    // split-tile scratch (zeroed with the counters): a tile qualifies with > SPLIT_MIN of the <= cap records
+    L.split_slots = L.split_items = 0;
+    if (G == 1 && split_enabled() && cap > SPLIT_MIN) {
+        long long slots = cap / SPLIT_MIN + 1;
+        if (slots > 128) slots = 128;
+        const size_t TV = (size_t)1 << (s0 + s1 + s2);
+        L.split_slots = (int)slots;
+        L.split_items = (int)(cap / SPLIT_PART + (n_keys / G) + slots + 1);      // parts + whole tiles
+        L.slot_count = off; off = align_up(off + (size_t)slots * 4, 256);
+        L.slot_ws = off; off = align_up(off + (size_t)slots * TV * 24, 256);
+        L.slot_u = off; off = align_up(off + (size_t)slots * TV * g->channels * 8, 256);
+        L.slot_bits = off; off = align_up(off + (size_t)slots * ((TV * g->channels + 31) / 32) * 4, 256);
+    } else {
+        L.slot_count = L.slot_ws = L.slot_u = L.slot_bits = off;
+    }
     L.active = off; off = align_up(off + (size_t)(n_keys / G) * TILE_CLASSES * 4, 256);
+    L.items = off; off = align_up(off + (size_t)L.split_items * 8, 256);
     L.rec = off; off = align_up(off + (size_t)cap * 16, 256);
     L.aux = off; off = align_up(off + (size_t)cap * 4, 256);
     L.total = off;
@@ -1059,7 +1312,12 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
 
     prof_mark(0, st);
     // cursor .. ticket are contiguous: one memset
-    MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, L.active - L.cursor, st));
+    // single-pass path: one group, class ids or ones (dense features keep the tile kernel)
+    const size_t single_lds = (P.feat_kind == MF_FEAT_ONES ? 0 : ((size_t)P.C << (P.s0 + P.s1 + P.s2)) * 8 +
+                                                                  ((((size_t)P.C << (P.s0 + P.s1 + P.s2)) + 31) / 32) * 4) +
+                              ((size_t)36 << (P.s0 + P.s1 + P.s2)) + 64;
+    const bool single = L.split_slots > 0 && P.feat_kind != MF_FEAT_DENSE_F32 && single_lds <= 80 * 1024;
+    MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, (single ? L.active : L.slot_count) - L.cursor, st));
     const dim3 bin_blocks = FRONT == 0 ? dim3((unsigned)(((P.H + PATCH - 1) / PATCH) * ((P.W + PATCH - 1) / PATCH)), (unsigned)P.n_frames)
                                        : dim3((unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS));
     hipLaunchKernelGGL(count_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
@@ -1072,7 +1330,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
                        P.cursor, P.n_keys + 1, (const int *)P.block_sums);
     MF_LAUNCH_CHECK("scan_apply_kernel");
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
-                       P.n_tiles, P.G, P.ticket, P.active);
+                       P.n_tiles, P.G, P.ticket, P.active, single ? SPLIT_MIN : 0, SPLIT_PART, L.split_slots,
+                       (int *)(ws + L.items));
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
@@ -1128,8 +1387,36 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         T.fx_shift = 62 - bits; if (T.fx_shift > 50) T.fx_shift = 50;
     }
     T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);
-    MF_LAUNCH_CHECK("fuse_tiles_kernel");
+    if (!single) {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);
+        MF_LAUNCH_CHECK("fuse_tiles_kernel");
+    } else {
+        SingleParams S;
+        S.size0 = P.size0; S.size1 = P.size1; S.size2 = P.size2; S.C = P.C; S.map = P.map; S.iw = P.iw;
+        S.s0 = P.s0; S.s1 = P.s1; S.s2 = P.s2; S.nt1 = P.nt1; S.nt2 = P.nt2; S.magicC = P.magicC; S.fx_shift = T.fx_shift;
+        S.cursor = P.cursor; S.ticket = P.ticket; S.items = (const int *)(ws + L.items); S.rec = P.rec; S.aux = P.aux;
+        S.slot_count = (int *)(ws + L.slot_count); S.slot_ws = (unsigned long long *)(ws + L.slot_ws);
+        S.slot_u = (unsigned long long *)(ws + L.slot_u);
+        S.slot_bits = (unsigned *)(ws + L.slot_bits);
+        const size_t slds = single_lds;
+        void (*sk)(SingleParams) = kind == 0 ? fuse_single_kernel<0, 512> : fuse_single_kernel<1, 512>;
+        if (slds > (size_t)dev.lds_per_cu) return fail(MF_ERR_INVALID, "single-pass tile needs %zu bytes of LDS", slds);
+        {
+            static std::mutex mu2;
+            static std::unordered_map<const void *, size_t> granted2;
+            std::lock_guard<std::mutex> lock(mu2);
+            size_t &have = granted2[(const void *)sk];
+            if (have < slds) {
+                MF_HIP_CHECK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+                have = slds;
+            }
+        }
+        int sper = (int)((size_t)dev.lds_per_cu / slds);
+        if (sper > 4) sper = 4;
+        if (sper < 1) sper = 1;
+        hipLaunchKernelGGL(sk, dim3(dev.cus * sper), dim3(512), slds, st, S);
+        MF_LAUNCH_CHECK("fuse_single_kernel");
+    }
     prof_mark(4, st);
     if (g_profile && g_ev_ready && g_prof_calls < PROF_CALLS) ++g_prof_calls;
     if (stamps) {
