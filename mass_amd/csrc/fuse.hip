@@ -301,7 +301,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(const int *__re
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int *data, int n, const int *__restrict__ block_sums)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int *data, int n, const int *__restrict__ block_sums,
+                                                                  int *nonempty /* += buckets with entries, or NULL */)
 {
     __shared__ int sh[SCAN_THREADS / 64];
     __shared__ int wsum[SCAN_THREADS / 64];
@@ -321,7 +322,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int *data, int
     int woff = 0;
     for (int w = 0; w < wid; ++w) woff += wsum[w];
     int run = pre + woff + inc - s;
-    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) { data[base + i] = run; run += v[i]; }
+    int filled = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) { data[base + i] = run; run += v[i]; filled += v[i] > 0; }
+    if (nonempty) {
+        const unsigned long long m = __ballot(filled > 0);
+        if (m) {                                        // few blocks see anything at all in a single-frame call
+            for (int o = 32; o > 0; o >>= 1) filled += __shfl_down(filled, o, 64);
+            if (lane == 0 && filled) atomicAdd(nonempty, filled);
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -337,19 +346,26 @@ __device__ __forceinline__ int tile_class(int n)
 }
 
 // Work items of fuse_single_kernel (single-group calls with class-id / ones features, split_min > 0):
-// every non-empty tile, a tile with more than split_min records cut into `nparts` record ranges.
-constexpr int SPLIT_ITEMS = ABORT_SLOT + 1, SPLIT_TILES = ABORT_SLOT + 2;
+// every non-empty tile, one with more than split_min records cut into `nparts` record ranges.
+constexpr int SPLIT_ITEMS = ABORT_SLOT + 1, SPLIT_TILES = ABORT_SLOT + 2, SPLIT_NONEMPTY = ABORT_SLOT + 3;
+constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
 constexpr int SPLIT_PARTS_MAX = 64;
 
 __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
                                                         int n_tiles, int G, int *ticket, int *active,
-                                                        int split_min, int split_part, int split_slots, int *items)
+                                                        int split_min, int split_part, int split_slots, int *items,
+                                                        int min_mean)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     int n = 0;
     if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
     if (t < n_tiles) n = cursor[(t + 1) * G] - cursor[t * G];
-    if (split_min > 0 && n > 0) {                   // single-pass kernel: every tile is an item, big ones in parts
+    // A call whose tiles are sparse on average (a synthetic frame of unrelated depths: ~40 records per
+    // tile) is better off in the tile kernel, which spends less per tile; a real frame (hundreds to
+    // thousands of records per tile) goes to the single-pass kernel.  The whole call goes one way.
+    // (With ones features the single-pass kernel has no per-class state and wins on both.)
+    if (split_min > 0 && (long long)cursor[n_tiles * G] < (long long)ticket[SPLIT_NONEMPTY] * min_mean) split_min = 0;
+    if (split_min > 0 && n > 0) {                   // single-pass kernel: every tile is an item, a big one several
         int nparts = 1, slot = 0xffff;
         if (n > split_min) {
             slot = atomicAdd(&ticket[SPLIT_TILES], 1);
@@ -559,6 +575,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     // wait (the old-map preload): nothing else is outstanding there, so reading the results of the
     // loads issued one tile earlier costs no wait of its own (vmcnt retires in order: waiting for an
     // old load at any other point would also wait for every younger load and store of the wave).
+    if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;      // nothing listed (uniform)
     int idx_pend = -1, act_pend = -1;                   // ticket drawn / work list entry being loaded
     if (tid == 0) {
 #pragma unroll
@@ -862,11 +879,12 @@ struct SingleParams {
     unsigned *slot_bits;               // [slots][ceil(TV * C / 32)] (voxel, class) pairs that met a sub-unit corner
 };
 
-template <int KIND, int NT>
+template <int KIND, int NT, bool STAMPS = false>
 __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x;
+    unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int C = P.C;
     const int sv = P.s0 + P.s1 + P.s2;
     const int TV = 1 << sv;
@@ -898,14 +916,23 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
     T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = C; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2;
     const int n_items = P.ticket[SPLIT_ITEMS];
 
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const int tile = P.items[2 * it], meta = P.items[2 * it + 1];
+    // the next item's descriptor and record range are looked up while the current item is processed
+    // (two dependent global round trips per item otherwise, which dominate when items are small)
+    int it = blockIdx.x, tile = -1, meta = 0, s = 0, e = 0;
+    if (it < n_items) {
+        tile = P.items[2 * it]; meta = P.items[2 * it + 1];
+        s = tile > 0 ? P.cursor[tile - 1] : 0; e = P.cursor[tile];               // one group: bucket key = tile
+    }
+    for (; it < n_items; it += gridDim.x) {
+        const int itn = it + gridDim.x;
+        int tile_n = -1, meta_n = 0, s_n = 0, e_n = 0;
+        if (itn < n_items) { tile_n = P.items[2 * itn]; meta_n = P.items[2 * itn + 1]; }
         const int part = meta & 255, nparts = (meta >> 8) & 255, slot = (meta >> 16) & 0xffff;
         const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
         const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
-        const int s = tile > 0 ? P.cursor[tile - 1] : 0, e = P.cursor[tile];      // one group: bucket key = tile
         const int len = (e - s + nparts - 1) / nparts;
         const int ea = s + part * len, eb = min(e, ea + len);
+        MF_STAMP(0)
         if (KIND == 1) {
             uint4 *z = reinterpret_cast<uint4 *>(U64);
             for (unsigned i = tid; i < (n_el >> 1); i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -914,7 +941,23 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
         for (int v = tid; v < TV; v += NT) { W64[v] = 0ull; S64[v] = 0ull; T64[v] = 0ull; }
         for (int k = tid; k < n_bits; k += NT) bits[k] = 0u;
         __syncthreads();
-        for (int q = ea + tid; q < eb; q += NT) {
+        MF_STAMP(1)
+        // Neighbouring records come from neighbouring pixels and hit the same voxels: a wave taking 64
+        // consecutive records would pile its lanes onto a handful of LDS words per atomic.  The records
+        // are therefore dealt to the lanes with a stride (a multiplicative permutation of the range).
+        const int nrec = eb - ea;
+        int mulk = 1;
+        if (nrec > 64) {
+            mulk = 61;
+            while (true) {                                    // smallest of a few odd multipliers coprime with nrec
+                int a_ = mulk, b_ = nrec;
+                while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
+                if (a_ == 1) break;
+                mulk += 2;
+            }
+        }
+        for (int q0 = tid; q0 < nrec; q0 += NT) {
+            const int q = ea + (int)(((long long)q0 * mulk) % nrec);
             const uint4 r = P.rec[q];
             const uint32_t label = KIND == 1 ? P.aux[q] : 0u;
             for_corners(T, r, o0, o1, o2, [&](int v, float w) {
@@ -930,6 +973,8 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
             });
         }
         __syncthreads();
+        MF_STAMP(2)
+        if (tile_n >= 0) { s_n = tile_n > 0 ? P.cursor[tile_n - 1] : 0; e_n = P.cursor[tile_n]; }
         bool finish = true;
         unsigned long long *ws = nullptr, *us = nullptr;
         if (nparts > 1) {
@@ -965,6 +1010,7 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
                 __syncthreads();
             }
         }
+        MF_STAMP(3)
         if (finish) {
             // per voxel: a, the factor that turns the integer U[c] into the added value g * U[c], and
             // what a class that only met sub-unit corners gets
@@ -992,6 +1038,7 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
                 sa[v] = a; sg[v] = g; st[v] = t;
             }
             __syncthreads();
+            MF_STAMP(4)
             // read-modify-write of the touched voxels, FB elements per thread at a time with all their
             // loads in flight before the first use (the loop is otherwise one HBM latency per element)
             constexpr int FB = 8;
@@ -1027,6 +1074,8 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
             }
         }
         __syncthreads();
+        MF_STAMP(5)
+        tile = tile_n; meta = meta_n; s = s_n; e = e_n;
     }
 }
 
@@ -1167,8 +1216,18 @@ struct Layout {
     long long cap;
 };
 
-constexpr int SPLIT_MIN = 1536;        // a tile with more records (single group) is cut into parts ...
-constexpr int SPLIT_PART = 1024;       // ... of about this many records
+// a tile with more than split_min() records (single group) is cut into parts of about split_part()
+// records; MF_SPLIT_MIN / MF_SPLIT_PART override them for experiments
+static int split_min()
+{
+    static const int v = getenv("MF_SPLIT_MIN") ? atoi(getenv("MF_SPLIT_MIN")) : 8192;
+    return v > 64 ? v : 64;
+}
+static int split_part()
+{
+    static const int v = getenv("MF_SPLIT_PART") ? atoi(getenv("MF_SPLIT_PART")) : 4096;
+    return v > 64 ? v : 64;
+}
 
 static bool split_enabled()
 {
@@ -1194,12 +1253,12 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
     L.ticket = off; off = align_up(off + 256, 256);
     // split-tile scratch (zeroed with the counters): a tile qualifies with > SPLIT_MIN of the <= cap records
     L.split_slots = L.split_items = 0;
-    if (G == 1 && split_enabled() && cap > SPLIT_MIN) {
-        long long slots = cap / SPLIT_MIN + 1;
+    if (G == 1 && split_enabled() && cap > split_min()) {
+        long long slots = cap / split_min() + 1;
         if (slots > 128) slots = 128;
         const size_t TV = (size_t)1 << (s0 + s1 + s2);
         L.split_slots = (int)slots;
-        L.split_items = (int)(cap / SPLIT_PART + (n_keys / G) + slots + 1);      // parts + whole tiles
+        L.split_items = (int)(cap / split_part() + (n_keys / G) + slots + 1);    // parts + whole tiles
         L.slot_count = off; off = align_up(off + (size_t)slots * 4, 256);
         L.slot_ws = off; off = align_up(off + (size_t)slots * TV * 24, 256);
         L.slot_u = off; off = align_up(off + (size_t)slots * TV * g->channels * 8, 256);
@@ -1327,11 +1386,11 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
                        (const int *)P.cursor, P.n_keys + 1, P.block_sums);
     MF_LAUNCH_CHECK("scan_sums_kernel");
     hipLaunchKernelGGL(scan_apply_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
-                       P.cursor, P.n_keys + 1, (const int *)P.block_sums);
+                       P.cursor, P.n_keys + 1, (const int *)P.block_sums, single ? P.ticket + SPLIT_NONEMPTY : (int *)nullptr);
     MF_LAUNCH_CHECK("scan_apply_kernel");
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
-                       P.n_tiles, P.G, P.ticket, P.active, single ? SPLIT_MIN : 0, SPLIT_PART, L.split_slots,
-                       (int *)(ws + L.items));
+                       P.n_tiles, P.G, P.ticket, P.active, single ? split_min() : 0, split_part(), L.split_slots,
+                       (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN);
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
@@ -1387,10 +1446,9 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         T.fx_shift = 62 - bits; if (T.fx_shift > 50) T.fx_shift = 50;
     }
     T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
-    if (!single) {
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);
-        MF_LAUNCH_CHECK("fuse_tiles_kernel");
-    } else {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);      // returns at once when the call went to the single-pass kernel
+    MF_LAUNCH_CHECK("fuse_tiles_kernel");
+    if (single) {
         SingleParams S;
         S.size0 = P.size0; S.size1 = P.size1; S.size2 = P.size2; S.C = P.C; S.map = P.map; S.iw = P.iw;
         S.s0 = P.s0; S.s1 = P.s1; S.s2 = P.s2; S.nt1 = P.nt1; S.nt2 = P.nt2; S.magicC = P.magicC; S.fx_shift = T.fx_shift;
@@ -1399,7 +1457,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         S.slot_u = (unsigned long long *)(ws + L.slot_u);
         S.slot_bits = (unsigned *)(ws + L.slot_bits);
         const size_t slds = single_lds;
-        void (*sk)(SingleParams) = kind == 0 ? fuse_single_kernel<0, 512> : fuse_single_kernel<1, 512>;
+        void (*sk)(SingleParams) = stamps ? (kind == 0 ? fuse_single_kernel<0, 512, true> : fuse_single_kernel<1, 512, true>)
+                                          : (kind == 0 ? fuse_single_kernel<0, 512> : fuse_single_kernel<1, 512>);
         if (slds > (size_t)dev.lds_per_cu) return fail(MF_ERR_INVALID, "single-pass tile needs %zu bytes of LDS", slds);
         {
             static std::mutex mu2;
@@ -1424,6 +1483,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         MF_HIP_CHECK(hipStreamSynchronize(st));
         MF_HIP_CHECK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_stamps), sizeof(z)));
         double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)z[i];
+        if (single) fprintf(stderr, "[MF_STAMPS] single-pass kernel: item fetch / zero / accumulate / merge+arrive / per-voxel / read-modify-write =\n");
         fprintf(stderr, "[MF_STAMPS] blocks=%d nt=%d lds=%zu gc=%d | ticket+offs %.1f%% setup %.1f%% chunk-zero %.1f%% P1 %.1f%% P2 %.1f%% P3 %.1f%% final %.1f%% | total %.3g ticks/block\n",
                 blocks, nt, lds, P.gc, 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot,
                 100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot, tot / blocks);
