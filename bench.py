@@ -304,19 +304,20 @@ def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
         torch.cuda.synchronize()
         sem.check_labels()
         return time.perf_counter() - t0
-    run_traj(False)
-    dt = min(run_traj(False) for _ in range(2))
-    dt_defer = min(run_traj(False, validate="defer") for _ in range(2))
+    run_traj(False, validate="defer")
+    dt = min(run_traj(False, validate="defer") for _ in range(2))
+    dt_sync = min(run_traj(False, validate=True) for _ in range(2))
     d_np, s_np, c_np = tr["depth"].numpy(), tr["semantic"].numpy()[..., None].astype(np.int64), tr["rgb"].numpy()
-    dt_host = run_traj(True)
+    dt_host = run_traj(True, validate="defer")
     out["config3_trajectory_300x3maps"] = dict(
         frames_per_s=n3 / dt, ms_per_frame_3_maps=dt / n3 * 1e3, updates_per_s=3 * n3 / dt,
-        frames_per_s_deferred_label_check=n3 / dt_defer,
+        frames_per_s_synchronous_label_check=n3 / dt_sync,
         host_fed_frames_per_s=n3 / dt_host, host_fed_ms_per_frame=dt_host / n3 * 1e3,
         note="per-frame layer.update() on occupancy (C=1), semantic (C=54 labels) and RGB (C=3 dense fp32) maps, "
              "256^3 each, sequential; frames_per_s with observations resident in HBM and the default class-id check "
-             "(update() waits for the semantic update to learn whether an id was out of range, as the reference's "
-             "one_hot does), frames_per_s_deferred_label_check with validate='defer' (no wait), host_fed_* with numpy "
+             "(validate='defer': an id out of range calls the update off on the device and raises at the next call into "
+             "the layer), frames_per_s_synchronous_label_check with validate=True (update() waits for the semantic "
+             "update and raises itself, like the reference's one_hot), host_fed_* with numpy "
              "observations uploaded per call (PCIe inclusive, int64 label image as the simulator produces it)")
     del occ, sem, rgb, d_dev, s_dev, c_dev
 

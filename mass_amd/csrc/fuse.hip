@@ -765,7 +765,22 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                 while (lpe < C && lpe < 64) lpe <<= 1;
                 const int sub = tid & (lpe - 1);
                 const int per = NT / lpe;
-                for (int e = ea + tid / lpe; e < eb; e += per) {
+                // neighbouring records hit the same voxels (neighbouring pixels): dealt in order, the
+                // lanes of a wave would meet on a few LDS words and lose the compare-and-swap to each
+                // other; a multiplicative permutation of the range spreads them
+                const int nrec = eb - ea;
+                int mulk = 1;
+                if (nrec > 64) {
+                    mulk = 61;
+                    for (;;) {
+                        int a_ = mulk, b_ = nrec;
+                        while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
+                        if (a_ == 1) break;
+                        mulk += 2;
+                    }
+                }
+                for (int e0 = tid / lpe; e0 < nrec; e0 += per) {
+                    const int e = ea + (int)(((long long)e0 * mulk) % nrec);
                     const uint4 r = P.rec[e];
                     const float *f = (const float *)P.feat + (size_t)P.aux[e] * C;
                     const int base = slot_of(e) * TV;

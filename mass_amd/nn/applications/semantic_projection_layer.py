@@ -56,6 +56,7 @@ class SemanticProjectionLayer(BaseProjectionLayer):
             self.class_to_colors = None
 
     def reset(self, origin_y: float = 0.0, origin_x: float = 0.0, origin_z: float = 0.0):
+        self.check_labels(synchronize=False)
         self.boxes = None
         super(SemanticProjectionLayer, self).reset(
             origin_y=origin_y, origin_x=origin_x, origin_z=origin_z)
@@ -104,15 +105,16 @@ class SemanticProjectionLayer(BaseProjectionLayer):
             self.check_labels(synchronize=True)
         return self
 
-    def update(self, observation: Dict[str, torch.Tensor], validate=True):
+    def update(self, observation: Dict[str, torch.Tensor], validate="defer"):
         """semantic_projection_layer.py:165-216.  Class ids outside [0, feature_size) raise like the
         reference's one_hot (:203-209) and leave the map untouched: the kernels detect them and call
-        the update off; validate=True (default) waits for the update to learn that, "defer" reports
-        it at the next update / check_labels() instead (no wait), False skips the check (such ids
-        then count as an all-zero feature row)."""
+        the update off.  validate="defer" (default) does not wait for the GPU: the RuntimeError
+        surfaces at the next update() / find() / reset() / check_labels() of this layer, the way
+        device-side errors usually do; validate=True waits for the update and raises from this very
+        call; False skips the check (such ids then count as an all-zero feature row)."""
         return self._update(observation, True, validate)
 
-    def update_batch(self, observation: Dict[str, torch.Tensor], sequential: bool = True, validate=True):
+    def update_batch(self, observation: Dict[str, torch.Tensor], sequential: bool = True, validate="defer"):
         return self._update(observation, sequential, validate)
 
     # ------------------------------------------------------------------ find
@@ -140,6 +142,7 @@ class SemanticProjectionLayer(BaseProjectionLayer):
         world position, confidence, size in voxels and (optionally) the expected feature vector
         (semantic_projection_layer.py:257-362).  Returns (confidences, coordinates, sizes,
         features or None) as lists of tensors, one entry per detection."""
+        self.check_labels(synchronize=False)
         data = self.data
         c = int(semantic_category)
         if contour_padding == 0:

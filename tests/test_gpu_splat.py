@@ -235,16 +235,21 @@ def test_out_of_range_class_ids_raise_and_leave_the_map_untouched(device):
         bad = good.clone().to(dtype)
         bad[H // 2, W // 2, 0] = bad_value
         with pytest.raises(RuntimeError, match="Class values"):
-            lay.update(dict(obs, semantic=bad))
+            lay.update(dict(obs, semantic=bad), validate=True)
         assert torch.equal(lay.data, before)                      # the update was called off as a whole
     lay.update(dict(obs, semantic=good))                           # and the layer keeps working
     assert not torch.equal(lay.data, before)
     # deferred: reported by the next call (or check_labels), map untouched by the bad frame
     mid = lay.data.clone()
     bad = good.clone(); bad[0, 0, 0] = C
-    lay.update(dict(obs, semantic=bad), validate="defer")
+    lay.update(dict(obs, semantic=bad))                            # default: validate="defer"
     with pytest.raises(RuntimeError, match="Class values"):
         lay.check_labels()
+    assert torch.equal(lay.data, mid)
+    lay.update(dict(obs, semantic=bad))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="Class values"):        # ... or the next call into the layer
+        lay.update(dict(obs, semantic=good))
     assert torch.equal(lay.data, mid)
     # unchecked: the id stands for an all-zero feature row (still decays what it lands on)
     ref = orc.RefProjectionLayer(**kw)
