@@ -348,6 +348,8 @@ __device__ __forceinline__ int tile_class(int n)
 // Work items of fuse_single_kernel (single-group calls with class-id / ones features, split_min > 0):
 // every non-empty tile, one with more than split_min records cut into `nparts` record ranges.
 constexpr int SPLIT_ITEMS = ABORT_SLOT + 1, SPLIT_TILES = ABORT_SLOT + 2, SPLIT_NONEMPTY = ABORT_SLOT + 3;
+constexpr int FEAT_ABSMAX = ABORT_SLOT + 4;     // bits of max |feature| of the call (dense single-pass path)
+constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
 constexpr int SPLIT_PARTS_MAX = 64;
 
@@ -888,6 +890,7 @@ struct SingleParams {
     const int *items;
     const uint4 *rec;
     const uint32_t *aux;
+    const float *feat;                 // dense features (fuse_single_dense_kernel)
     int *slot_count;                   // [slots] parts arrived
     unsigned long long *slot_ws;       // [slots][TV][2] W, S2
     unsigned long long *slot_u;        // [slots][TV * C] U (labels only; ones: U = S2)
@@ -1091,6 +1094,145 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
         __syncthreads();
         MF_STAMP(5)
         tile = tile_n; meta = meta_n; s = s_n; e = e_n;
+    }
+}
+
+// max |x| over a dense feature image, as float bits in *out (non-negative floats order like their bits)
+__global__ __launch_bounds__(256) void feat_absmax_kernel(const float *__restrict__ f, long long n, int *out)
+{
+    unsigned m = 0u;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        m = max(m, __float_as_uint(f[i]) & 0x7fffffffu);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned *>(out), m);
+}
+
+// The same single pass for dense fp32 features of few channels (an RGB map): U[c] = sum w^2 feat[c]
+// as SIGNED 64-bit fixed point.  The scale comes from the call's largest |feature| (found by
+// feat_absmax_kernel), sub-unit terms go to a second sum with 34 more fraction bits, like the
+// squares of the class-id path.  Tiles are taken whole (no parts).
+template <int NT>
+__global__ __launch_bounds__(NT) void fuse_single_dense_kernel(SingleParams P)
+{
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x;
+    const int C = P.C;
+    const int sv = P.s0 + P.s1 + P.s2;
+    const int TV = 1 << sv;
+    const unsigned n_el = (unsigned)TV * (unsigned)C;
+    unsigned long long *U64 = reinterpret_cast<unsigned long long *>(smem);     // [TV][C] signed
+    unsigned long long *V64 = U64 + n_el;                                        // [TV][C] signed, sub-unit terms
+    unsigned long long *W64 = V64 + n_el;                                        // [TV]
+    unsigned long long *S64 = W64 + TV;                                          // [TV]
+    unsigned long long *T64 = S64 + TV;                                          // [TV]
+    float *sa = reinterpret_cast<float *>(T64 + TV);                             // [TV]
+    float *sg = sa + TV;                                                         // [TV]
+    const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
+    const int fx_c = 182 - P.fx_shift, fx_c2 = fx_c - 34;
+    const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);
+    const float fx_inv2 = fx_inv * 5.8207661e-11f;                               // 2^-34
+    // |w^2 * feat| < 2^E with E from the largest |feature|: U gets fx_shift - E fraction bits
+    const unsigned mx = (unsigned)P.ticket[FEAT_ABSMAX];
+    int E = mx ? (int)(mx >> 23) - 126 : 0;
+    int shift_u = P.fx_shift - E;
+    shift_u = shift_u > 56 ? 56 : (shift_u < 4 ? 4 : shift_u);
+    const int ux_c = 182 - shift_u, ux_c2 = ux_c - 34;
+    const float ux_inv = __uint_as_float((unsigned)(127 - shift_u) << 23);
+    const float ux_inv2 = ux_inv * 5.8207661e-11f;
+    TileParams T;
+    T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = C; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2;
+    const int n_items = P.ticket[SPLIT_ITEMS];
+
+    int it = blockIdx.x, tile = -1, s = 0, e = 0;
+    if (it < n_items) { tile = P.items[2 * it]; s = tile > 0 ? P.cursor[tile - 1] : 0; e = P.cursor[tile]; }
+    for (; it < n_items; it += gridDim.x) {
+        const int itn = it + gridDim.x;
+        int tile_n = -1, s_n = 0, e_n = 0;
+        if (itn < n_items) tile_n = P.items[2 * itn];
+        const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
+        const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(U64);                           // U64, V64 are adjacent
+            for (unsigned i = tid; i < n_el; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        for (int v = tid; v < TV; v += NT) { W64[v] = 0ull; S64[v] = 0ull; T64[v] = 0ull; }
+        __syncthreads();
+        const int nrec = e - s;
+        int mulk = 1;
+        if (nrec > 64) {                                       // strided dealing, as in fuse_single_kernel
+            mulk = 61;
+            for (;;) {
+                int a_ = mulk, b_ = nrec;
+                while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
+                if (a_ == 1) break;
+                mulk += 2;
+            }
+        }
+        for (int q0 = tid; q0 < nrec; q0 += NT) {
+            const int q = s + (int)(((long long)q0 * mulk) % nrec);
+            const uint4 r = P.rec[q];
+            const float *f = P.feat + (size_t)P.aux[q] * C;
+            for_corners(T, r, o0, o1, o2, [&](int v, float w) {
+                const float ww = w * w;
+                const unsigned long long w2 = to_fixed(ww, fx_c);
+                atomicAdd(&W64[v], to_fixed(w, fx_c));
+                if (w2 != 0ull) atomicAdd(&S64[v], w2);
+                else atomicAdd(&T64[v], to_fixed(ww, fx_c2));
+                for (int c = 0; c < C; ++c) {
+                    const float x = ww * f[c];
+                    const float ax = fabsf(x);
+                    if (!(ax < 3.0e38f)) continue;                  // inf / NaN features are not representable here
+                    unsigned long long m = to_fixed(ax, ux_c);
+                    unsigned long long *dst = &U64[v * C + c];
+                    if (m == 0ull) { m = to_fixed(ax, ux_c2); dst = &V64[v * C + c]; }
+                    if (m != 0ull) atomicAdd(dst, x < 0.0f ? 0ull - m : m);
+                }
+            });
+        }
+        __syncthreads();
+        if (tile_n >= 0) { s_n = tile_n > 0 ? P.cursor[tile_n - 1] : 0; e_n = P.cursor[tile_n]; }
+        for (int v = tid; v < TV; v += NT) {
+            const unsigned long long wq = W64[v];
+            float a = 1.0f, g = 0.0f;
+            if (wq != 0ull) {
+                const float Wv = (float)wq * fx_inv;
+                const float S2 = (float)S64[v] * fx_inv + (float)T64[v] * fx_inv2;
+                const float rW = __builtin_amdgcn_rcpf(Wv);
+                a = 1.0f - P.iw * (S2 * rW);
+                g = P.iw * rW;
+            }
+            sa[v] = a; sg[v] = g;
+        }
+        __syncthreads();
+        constexpr int FB = 4;
+        for (unsigned b0 = 0; b0 < n_el; b0 += NT * FB) {
+            float old[FB], add[FB], av[FB];
+            size_t gi[FB];
+            bool on[FB];
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const unsigned i = b0 + j * NT + tid;
+                on[j] = false;
+                if (i < n_el) {
+                    const unsigned v = div_magic(i, P.magicC);
+                    const float g = sg[v];
+                    if (g != 0.0f) {
+                        const unsigned c = i - v * C;
+                        const int l2 = v & m2, l1 = (v >> P.s2) & m1, l0 = v >> (P.s1 + P.s2);
+                        gi[j] = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + (o2 + l2)) * C + c;
+                        old[j] = P.map[gi[j]];
+                        add[j] = g * ((float)(long long)U64[i] * ux_inv + (float)(long long)V64[i] * ux_inv2);
+                        av[j] = sa[v];
+                        on[j] = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FB; ++j)
+                if (on[j]) P.map[gi[j]] = av[j] * old[j] + add[j];
+        }
+        __syncthreads();
+        tile = tile_n; s = s_n; e = e_n;
     }
 }
 
@@ -1387,15 +1529,22 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     prof_mark(0, st);
     // cursor .. ticket are contiguous: one memset
     // single-pass path: one group, class ids or ones (dense features keep the tile kernel)
-    const size_t single_lds = (P.feat_kind == MF_FEAT_ONES ? 0 : ((size_t)P.C << (P.s0 + P.s1 + P.s2)) * 8 +
+    const bool dense = P.feat_kind == MF_FEAT_DENSE_F32;
+    const size_t single_lds = (P.feat_kind == MF_FEAT_ONES ? 0 : ((size_t)P.C << (P.s0 + P.s1 + P.s2)) * (dense ? 16 : 8) +
                                                                   ((((size_t)P.C << (P.s0 + P.s1 + P.s2)) + 31) / 32) * 4) +
                               ((size_t)36 << (P.s0 + P.s1 + P.s2)) + 64;
-    const bool single = L.split_slots > 0 && P.feat_kind != MF_FEAT_DENSE_F32 && single_lds <= 80 * 1024;
+    const bool single = L.split_slots > 0 && (!dense || P.C <= SINGLE_DENSE_MAX_C) && single_lds <= 80 * 1024;
     MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, (single ? L.active : L.slot_count) - L.cursor, st));
     const dim3 bin_blocks = FRONT == 0 ? dim3((unsigned)(((P.H + PATCH - 1) / PATCH) * ((P.W + PATCH - 1) / PATCH)), (unsigned)P.n_frames)
                                        : dim3((unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS));
     hipLaunchKernelGGL(count_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
+    if (single && dense) {
+        const long long nf = FRONT == 0 ? (long long)P.n_frames * P.fh * P.fw * P.C : P.n_points * P.C;
+        hipLaunchKernelGGL(feat_absmax_kernel, dim3((unsigned)((nf + 256 * 16 - 1) / (256 * 16) > 1024 ? 1024 : (nf + 256 * 16 - 1) / (256 * 16))),
+                           dim3(256), 0, st, (const float *)P.feat, nf, P.ticket + FEAT_ABSMAX);
+        MF_LAUNCH_CHECK("feat_absmax_kernel");
+    }
     prof_mark(1, st);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
                        (const int *)P.cursor, P.n_keys + 1, P.block_sums);
@@ -1404,7 +1553,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
                        P.cursor, P.n_keys + 1, (const int *)P.block_sums, single ? P.ticket + SPLIT_NONEMPTY : (int *)nullptr);
     MF_LAUNCH_CHECK("scan_apply_kernel");
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
-                       P.n_tiles, P.G, P.ticket, P.active, single ? split_min() : 0, split_part(), L.split_slots,
+                       P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
                        (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN);
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
@@ -1468,12 +1617,14 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         S.size0 = P.size0; S.size1 = P.size1; S.size2 = P.size2; S.C = P.C; S.map = P.map; S.iw = P.iw;
         S.s0 = P.s0; S.s1 = P.s1; S.s2 = P.s2; S.nt1 = P.nt1; S.nt2 = P.nt2; S.magicC = P.magicC; S.fx_shift = T.fx_shift;
         S.cursor = P.cursor; S.ticket = P.ticket; S.items = (const int *)(ws + L.items); S.rec = P.rec; S.aux = P.aux;
+        S.feat = (const float *)P.feat;
         S.slot_count = (int *)(ws + L.slot_count); S.slot_ws = (unsigned long long *)(ws + L.slot_ws);
         S.slot_u = (unsigned long long *)(ws + L.slot_u);
         S.slot_bits = (unsigned *)(ws + L.slot_bits);
         const size_t slds = single_lds;
-        void (*sk)(SingleParams) = stamps ? (kind == 0 ? fuse_single_kernel<0, 512, true> : fuse_single_kernel<1, 512, true>)
-                                          : (kind == 0 ? fuse_single_kernel<0, 512> : fuse_single_kernel<1, 512>);
+        void (*sk)(SingleParams) = dense ? fuse_single_dense_kernel<512>
+                                   : stamps ? (kind == 0 ? fuse_single_kernel<0, 512, true> : fuse_single_kernel<1, 512, true>)
+                                            : (kind == 0 ? fuse_single_kernel<0, 512> : fuse_single_kernel<1, 512>);
         if (slds > (size_t)dev.lds_per_cu) return fail(MF_ERR_INVALID, "single-pass tile needs %zu bytes of LDS", slds);
         {
             static std::mutex mu2;
