@@ -56,6 +56,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames per repetition of the CPU oracle (1 warm + 3 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other SURVEY 8(d) workloads (rank 0, N = 1)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="issue every step as one mf_fuse_frames call instead of overlapping the bucketing of step k+1 "
+                         "with the tile kernels of step k (mf_fuse_frames_stage / _commit on two streams)")
     ap.add_argument("--rank-seed-stride", type=int, default=-1,
                     help="rank r draws its frames from seeds r*stride.. (default: the batch size, i.e. disjoint "
                          "episodes per rank; 0 gives every rank the same frames, used by the 2-rank rehearsal test)")
@@ -380,11 +383,21 @@ def run_rank(args):
     sequential = args.mode == "sequential"
 
     from mass_amd import _lib
-    from mass_amd.utils.projection import fuse_frames
+    from mass_amd.utils.projection import fuse_frames, FusePipeline
+
+    pipe = None if args.no_pipeline else FusePipeline(dev)
 
     def step():
-        fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, label, lay.data,
-                    interpolation_weight=lay.interpolation_weight, sequential=sequential, workspace=lay._workspace)
+        if pipe is None:
+            fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, label, lay.data,
+                        interpolation_weight=lay.interpolation_weight, sequential=sequential, workspace=lay._workspace)
+        else:       # stages this step's batch on the side stream, commits the previous step's
+            pipe.submit(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, label, lay.data,
+                        interpolation_weight=lay.interpolation_weight, sequential=sequential)
+
+    def drain():
+        if pipe is not None:
+            pipe.flush()
 
     def barrier():
         torch.cuda.synchronize()
@@ -393,6 +406,7 @@ def run_rank(args):
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     _lib.check(_lib.lib.mf_profile_enable(1))
     n_prof = min(args.steps, 256)            # the library keeps events for 256 calls
@@ -401,7 +415,8 @@ def run_rank(args):
     t0 = time.perf_counter()
     ev0.record()
     for k in range(args.steps):
-        step()                     # stage events are recorded on the stream, nothing synchronises here
+        step()                     # stage events are recorded on the streams, nothing synchronises here
+    drain()                        # every one of the K steps is complete inside the timed region
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
@@ -438,14 +453,20 @@ def run_rank(args):
             "config": {"workload": f"configs[1]: {args.batch} x 480x640 depth + u8 54-class labels -> 256^3 x 54 "
                                    f"fp32 map at 0.05 m, distribution {dist_name}, {args.mode} blend"
                                    f"{' (= %d layer.update calls)' % args.batch if sequential else ''}, one map per GPU",
-                       "frames_per_step": args.batch, "map": [MAP, MAP, MAP, C], "mode": args.mode},
+                       "frames_per_step": args.batch, "map": [MAP, MAP, MAP, C], "mode": args.mode,
+                       "issue": ("one mf_fuse_frames call per step" if args.no_pipeline else
+                                 "steps pipelined: mf_fuse_frames_stage of step k+1 (bucketing, side stream) overlaps "
+                                 "mf_fuse_frames_commit of step k (tile kernels, in order); all K steps complete inside "
+                                 "the timed region")},
             "roofline": {"bound": "hbm", "kernel": "fuse_tiles_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": tile_bytes, "kernel_ms": fuse_ms,
                          "union_voxels": union,
                          "traffic_frac_of_peak": (traffic / (fuse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "note": "algorithmic bytes of the tile kernel = union over the launch's frames of the touched "
+                         "note": "kernel_ms is measured as the steps are timed (with the next step's bucketing kernels "
+                                 "sharing the CUs unless --no-pipeline); "
+                                 "algorithmic bytes of the tile kernel = union over the launch's frames of the touched "
                                  "voxels x C x 4 B x (1 read + 1 write): the launch keeps tiles in LDS across its "
                                  "frames, so each touched voxel has to cross HBM once each way; kernel_ms = mean "
                                  "HIP-event time of fuse_tiles over the timed steps (mf_profile_*, on the launch stream)"},

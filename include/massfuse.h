@@ -142,6 +142,17 @@ MF_API size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int
 MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
                    int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same update in two halves, for callers that fuse batch after batch: `stage` buckets the
+ * frames' points into the workspace (unproject, bin, count, scatter: the map is not read), `commit`
+ * applies a staged workspace to the map.  Staging batch k+1 on a second stream while batch k is
+ * being committed overlaps the two (the tile kernels leave half of the CUs' wave slots free);
+ * commits must stay in order on one stream, each workspace is owned by its batch from stage to
+ * the end of commit, and both calls take the same grid / frames / mode arguments. */
+MF_API int mf_fuse_frames_stage(const mf_grid *grid, const mf_frames *frames, int32_t mode,
+                         void *workspace, size_t workspace_bytes, void *stream);
+MF_API int mf_fuse_frames_commit(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
+                          int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
+
 /* update_feature_map, projection.py:233-351, for already binned points:
  * ind0/1/2 int64 and ratio0/1/2 fp32 device [n]; feat per feat_kind with one
  * row per point ([n] labels or [n][C] fp32).  Only grid->size*, channels and
@@ -194,7 +205,8 @@ MF_API int mf_roi_moments(const float *map, int32_t size0, int32_t size1, int32_
  * mf_update_feature_map calls records HIP events on its stream between its
  * stages, without synchronising.  mf_profile_read(call, ms) waits for profiled
  * call number `call` (0-based since the enable) and writes milliseconds
- *   ms[0] zero + count   ms[1] scan   ms[2] scatter   ms[3] fuse_tiles   ms[4] whole call;
+ *   ms[0] zero + count   ms[1] scan   ms[2] scatter   ms[3] tile kernels   ms[4] their sum
+ * (a stage / commit pair counts as one call, recorded when the commit is issued);
  * it returns the number of calls recorded so far, or <0.
  * Process-wide, not thread safe; off by default. */
 MF_API int mf_profile_enable(int32_t on);

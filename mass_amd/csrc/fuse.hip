@@ -1493,17 +1493,22 @@ static void fill_frames(FuseParams &P, const mf_frames *f)
 // the caller's stream between the pipeline stages of the most recent call.
 constexpr int PROF_CALLS = 256;
 static bool g_profile = false;
-static hipEvent_t g_ev[PROF_CALLS][5];
+static hipEvent_t g_ev[PROF_CALLS][6];
 static bool g_ev_ready = false;
-static int g_prof_calls = 0;       // profiled calls since mf_profile_enable(1)
+static int g_prof_calls = 0;       // profiled calls (commits) since mf_profile_enable(1)
+static int g_prof_stages = 0;      // stagings since then: the k-th staging and the k-th commit are one call
 
 static void prof_mark(int i, hipStream_t st)
 {
-    if (g_profile && g_ev_ready && g_prof_calls < PROF_CALLS) (void)hipEventRecord(g_ev[g_prof_calls][i], st);
+    const int slot = i <= 3 ? g_prof_stages : g_prof_calls;
+    if (g_profile && g_ev_ready && slot < PROF_CALLS) (void)hipEventRecord(g_ev[slot][i], st);
 }
 
 template <int FRONT>
-static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, size_t workspace_bytes, hipStream_t st)
+// phase: 1 = stage (bucket the points: memset, count, scan, tile list, scatter; the map is not touched),
+//        2 = commit (the tile kernels, on a workspace staged with the same arguments), 3 = both
+static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, size_t workspace_bytes, hipStream_t st,
+                        int phase = 3)
 {
     if (P.G < 1 || P.G > MAX_GROUPS)
         return fail(MF_ERR_INVALID, "at most %d sequential frames per call, got %d", MAX_GROUPS, P.G);
@@ -1526,17 +1531,18 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     P.n_tiles = P.nt0 * P.nt1 * P.nt2;
     P.n_keys = L.n_keys;
 
-    prof_mark(0, st);
-    // cursor .. ticket are contiguous: one memset
     // single-pass path: one group, class ids or ones (dense features keep the tile kernel)
     const bool dense = P.feat_kind == MF_FEAT_DENSE_F32;
     const size_t single_lds = (P.feat_kind == MF_FEAT_ONES ? 0 : ((size_t)P.C << (P.s0 + P.s1 + P.s2)) * (dense ? 16 : 8) +
                                                                   ((((size_t)P.C << (P.s0 + P.s1 + P.s2)) + 31) / 32) * 4) +
                               ((size_t)36 << (P.s0 + P.s1 + P.s2)) + 64;
     const bool single = L.split_slots > 0 && (!dense || P.C <= SINGLE_DENSE_MAX_C) && single_lds <= 80 * 1024;
-    MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, (single ? L.active : L.slot_count) - L.cursor, st));
     const dim3 bin_blocks = FRONT == 0 ? dim3((unsigned)(((P.H + PATCH - 1) / PATCH) * ((P.W + PATCH - 1) / PATCH)), (unsigned)P.n_frames)
                                        : dim3((unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS));
+    if (phase & 1) {
+    prof_mark(0, st);
+    // cursor .. ticket (.. split scratch) are contiguous: one memset
+    MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, (single ? L.active : L.slot_count) - L.cursor, st));
     hipLaunchKernelGGL(count_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
     if (single && dense) {
@@ -1560,9 +1566,16 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
     prof_mark(3, st);
+    if (g_profile && g_ev_ready && g_prof_stages < PROF_CALLS) ++g_prof_stages;
+    }
+    if (!(phase & 2)) return MF_OK;
+    prof_mark(4, st);
 
     const int sv = P.s0 + P.s1 + P.s2;
     P.gc = chunk_frames(P.C, sv, P.G);
+    // a commit on its own is meant to run beside the staging kernels of the next batch: one frame less per
+    // chunk leaves 8 KB of LDS per CU for their workgroups (with all of it taken they cannot start at all)
+    if (phase == 2 && P.gc > 2) P.gc -= 1;
     P.vec4 = ((uintptr_t)P.map % 16 == 0) && ((P.C << P.s2) % 4 == 0) && (P.size2 % (1 << P.s2) == 0) &&
              ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34));
     const size_t lds = tile_lds_bytes(P.C, sv, P.gc);
@@ -1642,7 +1655,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         hipLaunchKernelGGL(sk, dim3(dev.cus * sper), dim3(512), slds, st, S);
         MF_LAUNCH_CHECK("fuse_single_kernel");
     }
-    prof_mark(4, st);
+    prof_mark(5, st);
     if (g_profile && g_ev_ready && g_prof_calls < PROF_CALLS) ++g_prof_calls;
     if (stamps) {
         unsigned long long z[8];
@@ -1667,11 +1680,11 @@ int mf_profile_enable(int32_t on)
 {
     if (on && !g_ev_ready) {
         for (int c = 0; c < PROF_CALLS; ++c)
-            for (int i = 0; i < 5; ++i) MF_HIP_CHECK(hipEventCreate(&g_ev[c][i]));
+            for (int i = 0; i < 6; ++i) MF_HIP_CHECK(hipEventCreate(&g_ev[c][i]));
         g_ev_ready = true;
     }
     g_profile = on != 0;
-    if (on) g_prof_calls = 0;
+    if (on) g_prof_calls = g_prof_stages = 0;
     return MF_OK;
 }
 
@@ -1681,9 +1694,11 @@ int mf_profile_read(int32_t call, float *ms)
     if (call < 0 || call >= g_prof_calls)
         return fail(MF_ERR_INVALID, "call %d not recorded (%d profiled calls since mf_profile_enable(1))", call,
                     g_prof_calls);
-    MF_HIP_CHECK(hipEventSynchronize(g_ev[call][4]));
-    for (int i = 0; i < 4; ++i) MF_HIP_CHECK(hipEventElapsedTime(&ms[i], g_ev[call][i], g_ev[call][i + 1]));
-    MF_HIP_CHECK(hipEventElapsedTime(&ms[4], g_ev[call][0], g_ev[call][4]));
+    // events 0..3 bracket the staging kernels, 4..5 the tile kernels (possibly on another stream, later)
+    MF_HIP_CHECK(hipEventSynchronize(g_ev[call][5]));
+    for (int i = 0; i < 3; ++i) MF_HIP_CHECK(hipEventElapsedTime(&ms[i], g_ev[call][i], g_ev[call][i + 1]));
+    MF_HIP_CHECK(hipEventElapsedTime(&ms[3], g_ev[call][4], g_ev[call][5]));
+    ms[4] = ms[0] + ms[1] + ms[2] + ms[3];
     return g_prof_calls;
 }
 
@@ -1718,6 +1733,34 @@ int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpola
     P.G = mode == MF_MODE_SEQUENTIAL ? frames->n_frames : 1;
     P.iw = interpolation_weight;
     return run_pipeline<0>(P, grid, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static int fuse_frames_phase(const mf_grid *grid, const mf_frames *frames, float interpolation_weight, int32_t mode,
+                             void *workspace, size_t workspace_bytes, void *stream, int phase)
+{
+    int rc = check_grid(grid, true);
+    if (rc != MF_OK) return rc;
+    rc = check_frames(frames, grid->channels);
+    if (rc != MF_OK) return rc;
+    if (mode != MF_MODE_SEQUENTIAL && mode != MF_MODE_MERGED) return fail(MF_ERR_INVALID, "unknown mode %d", mode);
+    FuseParams P = {};
+    fill_grid(P, grid);
+    fill_frames(P, frames);
+    P.G = mode == MF_MODE_SEQUENTIAL ? frames->n_frames : 1;
+    P.iw = interpolation_weight;
+    return run_pipeline<0>(P, grid, workspace, workspace_bytes, (hipStream_t)stream, phase);
+}
+
+int mf_fuse_frames_stage(const mf_grid *grid, const mf_frames *frames, int32_t mode, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    return fuse_frames_phase(grid, frames, 0.0f, mode, workspace, workspace_bytes, stream, 1);
+}
+
+int mf_fuse_frames_commit(const mf_grid *grid, const mf_frames *frames, float interpolation_weight, int32_t mode,
+                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    return fuse_frames_phase(grid, frames, interpolation_weight, mode, workspace, workspace_bytes, stream, 2);
 }
 
 int mf_update_feature_map(const mf_grid *grid, int64_t n, const int64_t *ind0, const int64_t *ind1,

@@ -206,19 +206,10 @@ def update_feature_map(ind0, ind1, ind2, ratio0, ratio1, ratio2,
                                     current_stream(fm.device)))
 
 
-def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map,
-                interpolation_weight=0.5, sequential=True, min_ray_depth=0.0, max_ray_depth=10.0,
-                workspace=None, label_status=None):
-    """transform_rays + bin_rays + update_feature_map for a batch of posed
-    frames in one fused pipeline (what BaseProjectionLayer.update runs).
-
-    cam_rays [H, W, 3]; poses [B, 12] (pack_poses); depth [B, H, W(, 1)];
-    features: None (ones, C == 1), integer class ids [B, h, w] or fp32
-    [B, h, w, C] with h | H and w | W.  sequential=True reproduces B successive
-    layer.update() calls, False the functional API's merged batch.
-
-    label_status: optional pinned-host (or device) int32 tensor; the kernels set it to 1 and leave
-    the map untouched when a valid pixel carries a class id outside [0, C) (mf_frames.label_status)."""
+def _frames_call(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map,
+                 min_ray_depth, max_ray_depth, label_status):
+    """Argument blocks of the C ABI for a batch of posed frames: (grid struct, frames struct, B, H, W,
+    tensors that must stay alive until the call is issued)."""
     fm = _check_map(feature_map)
     require_device(bins_x, bins_y, bins_z, cam_rays, poses, depth, features)
     H, W = cam_rays.shape[0], cam_rays.shape[1]
@@ -244,6 +235,24 @@ def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, featur
         fr.feat_height, fr.feat_width = feat.shape[1], feat.shape[2]
     bx, by, bz = _f32c(bins_x), _f32c(bins_y), _f32c(bins_z)
     g = _grid_struct(fm, bx, by, bz)
+    return g, fr, fm, B, H, W, (depth, poses, feat, cam, bx, by, bz)
+
+
+def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map,
+                interpolation_weight=0.5, sequential=True, min_ray_depth=0.0, max_ray_depth=10.0,
+                workspace=None, label_status=None):
+    """transform_rays + bin_rays + update_feature_map for a batch of posed
+    frames in one fused pipeline (what BaseProjectionLayer.update runs).
+
+    cam_rays [H, W, 3]; poses [B, 12] (pack_poses); depth [B, H, W(, 1)];
+    features: None (ones, C == 1), integer class ids [B, h, w] or fp32
+    [B, h, w, C] with h | H and w | W.  sequential=True reproduces B successive
+    layer.update() calls, False the functional API's merged batch.
+
+    label_status: optional pinned-host (or device) int32 tensor; the kernels set it to 1 and leave
+    the map untouched when a valid pixel carries a class id outside [0, C) (mf_frames.label_status)."""
+    g, fr, fm, B, H, W, (depth, poses, feat, *_keep) = _frames_call(
+        bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map, min_ray_depth, max_ray_depth, label_status)
     ws = workspace or _default_workspace
     stream = current_stream(fm.device)
     step = _lib.MAX_FRAMES_PER_CALL if sequential else B
@@ -260,6 +269,68 @@ def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, featur
         check(lib.mf_fuse_frames(g, fr, float(interpolation_weight),
                                  _lib.MODE_SEQUENTIAL if sequential else _lib.MODE_MERGED,
                                  wptr, wbytes, stream))
+
+
+class FusePipeline:
+    """Batch after batch into one map with the bucketing of batch k+1 overlapped with the tile
+    kernels of batch k (mf_fuse_frames_stage on a side stream, mf_fuse_frames_commit in order on the
+    caller's stream; two workspaces).  Same results as calling fuse_frames per batch.
+
+        pipe = FusePipeline(device)
+        for batch in batches: pipe.submit(bins_x, ..., feature_map, ...)    # at most 256 frames each
+        pipe.flush()                                                         # commits the last batch
+    """
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.side = torch.cuda.Stream(self.device)
+        self.ws = [Workspace(), Workspace()]
+        self.staged = [torch.cuda.Event(), torch.cuda.Event()]
+        self.committed = [None, None]
+        self.pending = None          # (slot, grid, frames, iw, mode, wptr, wbytes, keep-alive tensors)
+        self.k = 0
+
+    def submit(self, bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map,
+               interpolation_weight=0.5, sequential=True, min_ray_depth=0.0, max_ray_depth=10.0, label_status=None):
+        g, fr, fm, B, H, W, keep = _frames_call(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map,
+                                                min_ray_depth, max_ray_depth, label_status)
+        if sequential and B > _lib.MAX_FRAMES_PER_CALL:
+            raise ValueError(f"at most {_lib.MAX_FRAMES_PER_CALL} sequential frames per submitted batch")
+        depth_t, poses_t, feat_t = keep[0], keep[1], keep[2]
+        fr.n_frames, fr.poses, fr.depth = B, poses_t.data_ptr(), depth_t.data_ptr()
+        fr.feat = feat_t.data_ptr() if feat_t is not None else None
+        mode = _lib.MODE_SEQUENTIAL if sequential else _lib.MODE_MERGED
+        need = lib.mf_fuse_workspace_bytes(g, B * H * W, B if sequential else 1)
+        if need == 0:
+            check(_lib.MF_ERR_INVALID)
+        slot = self.k & 1
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)                       # the inputs were produced on the caller's stream
+        if self.committed[slot] is not None:
+            self.side.wait_event(self.committed[slot])    # the workspace is free once its last commit is done
+        with torch.cuda.stream(self.side):
+            wptr, wbytes = self.ws[slot].get(need, self.device)
+            check(lib.mf_fuse_frames_stage(g, fr, mode, wptr, wbytes, _lib.c_void_p(self.side.cuda_stream)))
+            self.staged[slot].record(self.side)
+        mine = (slot, g, fr, float(interpolation_weight), mode, wptr, wbytes, keep, fm)
+        self._commit()                                    # the batch staged by the previous submit
+        self.pending = mine
+        self.k += 1
+
+    def _commit(self):
+        if self.pending is None:
+            return
+        slot, g, fr, iw, mode, wptr, wbytes, _keep, fm = self.pending
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(self.staged[slot])
+        check(lib.mf_fuse_frames_commit(g, fr, iw, mode, wptr, wbytes, _lib.c_void_p(main.cuda_stream)))
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.committed[slot] = ev
+        self.pending = None
+
+    def flush(self):
+        self._commit()
 
 
 def unproject_bin(bins_x, bins_y, bins_z, cam_rays, poses, depth, min_ray_depth=0.0, max_ray_depth=10.0):

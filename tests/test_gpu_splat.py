@@ -259,3 +259,37 @@ def test_out_of_range_class_ids_raise_and_leave_the_map_untouched(device):
     ref.update(dict(obs, features=onehot_bad))
     lay.update(dict(obs, semantic=bad), validate=False)
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="unchecked ids")
+
+
+def test_pipelined_batches_equal_plain_calls(device):
+    """FusePipeline (mf_fuse_frames_stage on a side stream overlapped with mf_fuse_frames_commit of the
+    previous batch) gives what one mf_fuse_frames call per batch gives, for sequential and merged
+    batches, labels and ones, and a single-frame batch (single-pass kernel)."""
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    from mass_amd.nn.applications.occupancy_projection_layer import OccupancyProjectionLayer
+    from mass_amd.utils.projection import fuse_frames, FusePipeline
+    H, W, C, M = SMALL["H"], SMALL["W"], 7, SMALL["MAP"]
+    kw = dict(camera_height=H, camera_width=W, map_height=M, map_width=M, map_depth=M, grid_resolution=SMALL["RES"])
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for nb in (3, 1, 5, 2):
+        batches.append(dict(position=0.2 * torch.randn(nb, 3, generator=g), yaw=6.28 * torch.rand(nb, generator=g),
+                            elevation=-0.6 * torch.rand(nb, generator=g), depth=(0.3 + 1.5 * torch.rand(nb, H, W, generator=g)).to(device),
+                            label=torch.randint(0, C, (nb, H, W), generator=g).to(torch.uint8).to(device)))
+    for kind in ("label", "ones"):
+        for sequential in (True, False):
+            mk = (lambda: SemanticProjectionLayer(feature_size=C, **kw).to(device)) if kind == "label" else \
+                 (lambda: OccupancyProjectionLayer(**kw).to(device))
+            a, b = mk(), mk()
+            pipe = FusePipeline(device)
+            for bt in batches:
+                poses = a._poses(bt["position"], bt["yaw"], bt["elevation"])
+                feat = bt["label"] if kind == "label" else None
+                fuse_frames(a.bins_x, a.bins_y, a.bins_z, a.rays, poses, bt["depth"], feat, a.data,
+                            interpolation_weight=0.5, sequential=sequential, workspace=a._workspace)
+                pipe.submit(b.bins_x, b.bins_y, b.bins_z, b.rays, poses, bt["depth"], feat, b.data,
+                            interpolation_weight=0.5, sequential=sequential)
+            pipe.flush()
+            torch.cuda.synchronize()
+            assert_map_close(b.data.cpu().numpy(), a.data.cpu().numpy(), what=f"{kind} sequential={sequential}")
+            assert float(a.data.abs().sum()) > 0
