@@ -352,13 +352,15 @@ constexpr int FEAT_ABSMAX = ABORT_SLOT + 4;     // bits of max |feature| of the 
 constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
 constexpr int SPLIT_PARTS_MAX = 64;
+constexpr long long SINGLE_MAX_POINTS = 1 << 21;   // calls with more points (a merged multi-frame batch) keep the tile kernel
 
 __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
                                                         int n_tiles, int G, int *ticket, int *active,
                                                         int split_min, int split_part, int split_slots, int *items,
-                                                        int min_mean)
+                                                        int min_mean, int first_ticket)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) ticket[0] = first_ticket;          // the tile kernel deals its first items statically (see there)
     int n = 0;
     if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
     if (t < n_tiles) n = cursor[(t + 1) * G] - cursor[t * G];
@@ -578,15 +580,20 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     // loads issued one tile earlier costs no wait of its own (vmcnt retires in order: waiting for an
     // old load at any other point would also wait for every younger load and store of the wave).
     if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;      // nothing listed (uniform)
+    // The first four work items of a workgroup are dealt statically, list positions b, b + n, b + 2n,
+    // b + 3n for workgroup b of n: the list is heaviest first, so every workgroup starts on one of the
+    // n heaviest tiles (four tickets drawn in a row would hand the four heaviest to one workgroup).
+    // tile_list_kernel starts the ticket counter at 4n.  A position past the end implies that all
+    // later ones of this workgroup are past it too.
     int idx_pend = -1, act_pend = -1;                   // ticket drawn / work list entry being loaded
     if (tid == 0) {
 #pragma unroll
         for (int c = 0; c < TILE_CLASSES; ++c) misc[4 + c] = P.ticket[1 + c];
-        const int i0 = atomicAdd(P.ticket, 1), i1 = atomicAdd(P.ticket, 1), i2 = atomicAdd(P.ticket, 1);
-        misc[0] = resolve(i0);
-        misc[3] = resolve(i1);
-        act_pend = resolve(i2);
-        idx_pend = atomicAdd(P.ticket, 1);
+        const int nb = gridDim.x, b = blockIdx.x;
+        misc[0] = resolve(b);
+        misc[3] = resolve(b + nb);
+        act_pend = resolve(b + 2 * nb);
+        idx_pend = b + 3 * nb;
     }
     __syncthreads();
     int tile = misc[0];
@@ -1410,7 +1417,8 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
     L.ticket = off; off = align_up(off + 256, 256);
     // split-tile scratch (zeroed with the counters): a tile qualifies with > SPLIT_MIN of the <= cap records
     L.split_slots = L.split_items = 0;
-    if (G == 1 && split_enabled() && cap > split_min()) {
+    // the single-pass path is for frame-sized calls; a large merged batch is the tile kernel's throughput regime
+    if (G == 1 && split_enabled() && cap > split_min() && n_points <= SINGLE_MAX_POINTS) {
         long long slots = cap / split_min() + 1;
         if (slots > 128) slots = 128;
         const size_t TV = (size_t)1 << (s0 + s1 + s2);
@@ -1539,6 +1547,28 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     const bool single = L.split_slots > 0 && (!dense || P.C <= SINGLE_DENSE_MAX_C) && single_lds <= 80 * 1024;
     const dim3 bin_blocks = FRONT == 0 ? dim3((unsigned)(((P.H + PATCH - 1) / PATCH) * ((P.W + PATCH - 1) / PATCH)), (unsigned)P.n_frames)
                                        : dim3((unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS));
+    // ---- configuration of the tile kernel (needed by both halves: its grid size seeds the ticket counter) ----
+    const int sv = P.s0 + P.s1 + P.s2;
+    P.gc = chunk_frames(P.C, sv, P.G);
+    // a commit on its own is meant to run beside the staging kernels of the next batch: one frame less per
+    // chunk leaves 8 KB of LDS per CU for their workgroups (with all of it taken they cannot start at all)
+    if (phase != 3 && P.gc > 2) P.gc -= 1;
+    P.vec4 = ((uintptr_t)P.map % 16 == 0) && ((P.C << P.s2) % 4 == 0) && (P.size2 % (1 << P.s2) == 0) &&
+             ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34));
+    const size_t lds = tile_lds_bytes(P.C, sv, P.gc);
+    const DeviceInfo &dev = device_info();
+    if (lds > (size_t)dev.lds_per_cu)
+        return fail(MF_ERR_INVALID, "tile needs %zu bytes of LDS, device has %d", lds, dev.lds_per_cu);
+    int nt = sv >= 9 ? 1024 : sv >= 7 ? 512 : 256;     // heavy tiles are bound by threads per tile
+    { int a, b, c; tile_override(a, b, c, nt); }
+    int per_cu = (int)((size_t)dev.lds_per_cu / lds);
+    if (per_cu > 16) per_cu = 16;
+    const int by_threads = 2048 / nt;
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu < 1) per_cu = 1;
+    int blocks = dev.cus * per_cu;
+    if (blocks > P.n_tiles) blocks = P.n_tiles;
+
     if (phase & 1) {
     prof_mark(0, st);
     // cursor .. ticket (.. split scratch) are contiguous: one memset
@@ -1560,7 +1590,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     MF_LAUNCH_CHECK("scan_apply_kernel");
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
                        P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
-                       (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN);
+                       (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks);
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
@@ -1571,26 +1601,6 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (!(phase & 2)) return MF_OK;
     prof_mark(4, st);
 
-    const int sv = P.s0 + P.s1 + P.s2;
-    P.gc = chunk_frames(P.C, sv, P.G);
-    // a commit on its own is meant to run beside the staging kernels of the next batch: one frame less per
-    // chunk leaves 8 KB of LDS per CU for their workgroups (with all of it taken they cannot start at all)
-    if (phase == 2 && P.gc > 2) P.gc -= 1;
-    P.vec4 = ((uintptr_t)P.map % 16 == 0) && ((P.C << P.s2) % 4 == 0) && (P.size2 % (1 << P.s2) == 0) &&
-             ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34));
-    const size_t lds = tile_lds_bytes(P.C, sv, P.gc);
-    const DeviceInfo &dev = device_info();
-    if (lds > (size_t)dev.lds_per_cu)
-        return fail(MF_ERR_INVALID, "tile needs %zu bytes of LDS, device has %d", lds, dev.lds_per_cu);
-    int nt = sv >= 9 ? 1024 : sv >= 7 ? 512 : 256;     // heavy tiles are bound by threads per tile
-    { int a, b, c; tile_override(a, b, c, nt); }
-    int per_cu = (int)((size_t)dev.lds_per_cu / lds);
-    if (per_cu > 16) per_cu = 16;
-    const int by_threads = 2048 / nt;
-    if (per_cu > by_threads) per_cu = by_threads;
-    if (per_cu < 1) per_cu = 1;
-    int blocks = dev.cus * per_cu;
-    if (blocks > P.n_tiles) blocks = P.n_tiles;
     const int kind = P.feat_kind == MF_FEAT_ONES ? 0 : (P.feat_kind == MF_FEAT_DENSE_F32 ? 2 : 1);
     void (*kern)(TileParams);
     if (nt <= 64) kern = kind == 0 ? fuse_tiles_kernel<0, 64> : kind == 1 ? fuse_tiles_kernel<1, 64> : fuse_tiles_kernel<2, 64>;
