@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round profile collection on the GPU box (run through gpurun): kernel trace + stats of the bench
+# command, then FETCH_SIZE / WRITE_SIZE / L2 hit counters in separate passes (the guide's recipe),
+# then the per-frame update path.  Summaries: python tools/summarize_profiles.py <tag>  (afterwards, here).
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof
+rm -rf $out && mkdir -p $out
+BENCH="python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o runc -- $BENCH > $out/bench_under_kt.json 2> $out/kt.err || exit 1
+echo "kernel trace done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o runc -- python3 bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $out/fetch.err || exit 1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o runc -- python3 bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $out/write.err || exit 1
+echo "write done"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $out/tcc -o runc -- python3 bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $out/tcc.err || exit 1
+echo "tcc done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_single -o runc -- python3 tools/bench_single.py 48 > $out/single_frame_updates.jsonl 2> $out/kt_single.err || exit 1
+echo "single-frame trace done"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/sq -o runc -- python3 bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline --no-pipeline > /dev/null 2> $out/sq.err || exit 1
+python3 tools/pmc_summary.py $out/sq mf:: > $out/sq_summary.txt
+echo "sq done"
+# summarise here (the raw traces are too bulky to travel back), keep the summaries only
+mkdir -p gpurun_out/prof_summary
+MF_PROFILE_OUT=gpurun_out/prof_summary python3 tools/summarize_profiles.py ${1:-r02} distA_sequential_b64 > gpurun_out/prof_summary/summary.log 2>&1 || { tail -5 gpurun_out/prof_summary/summary.log; exit 1; }
+cp $out/bench_under_kt.json gpurun_out/prof_summary/${1:-r02}_bench_under_rocprof.json
+cp $out/single_frame_updates.jsonl gpurun_out/prof_summary/${1:-r02}_single_frame_updates.jsonl
+cp $out/sq_summary.txt gpurun_out/prof_summary/${1:-r02}_sq_counters.txt
+rm -rf $out
+du -sh gpurun_out/prof_summary; ls gpurun_out/prof_summary

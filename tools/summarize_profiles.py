@@ -20,14 +20,17 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-workload_key = sys.argv[2] if len(sys.argv) > 2 else "distA_b64"
-out_dir = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+workload_key = sys.argv[2] if len(sys.argv) > 2 else "distA_sequential_b64"
+out_dir = os.environ.get("MF_PROFILE_OUT") or os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
 
 def one(pattern):
-    files = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    """Newest file matching <subdir>/**/<name> (rocprofv3 nests its output under host / pid directories)."""
+    sub, name = pattern.split("/", 1)
+    name = name.split("/")[-1]
+    files = sorted(glob.glob(os.path.join(src, sub, "**", name), recursive=True), key=os.path.getmtime)
     if not files:
         raise SystemExit(f"missing {pattern} under {src}")
     return files[-1]
@@ -44,6 +47,18 @@ with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as 
         r = dict(r)
         r["Name"] = r["Name"][:120]
         w.writerow(r)
+
+
+try:
+    srows = list(csv.DictReader(open(one("kt_single/runc/*_kernel_stats.csv"))))
+    with open(os.path.join(out_dir, f"{tag}_single_frame_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(srows[0].keys()))
+        w.writeheader()
+        for r in srows:
+            if "mf::" in r["Name"]:
+                r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
+except SystemExit:
+    pass
 
 
 def counter_means(path, counters):
@@ -79,12 +94,20 @@ summary["_pipeline_total_hbm_bytes_per_step"] = total
 with open(os.path.join(out_dir, f"{tag}_hbm_counters.json"), "w") as f:
     json.dump(summary, f, indent=1)
 
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel source hash: bench.py refuses traffic measured on other sources)
+
 tfile = os.path.join(out_dir, "traffic.json")
 traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
+if traffic.get("kernel_sources_sha16") != bench.sources_sha():
+    traffic = {}                       # measured on other kernel sources: start over
 fuse = [v for k, v in summary.items() if k.startswith("mf::fuse_tiles_kernel")]
+traffic["kernel_sources_sha16"] = bench.sources_sha()
 traffic[workload_key] = fuse[0]["hbm_bytes_per_launch"] if fuse else None
 traffic[workload_key + "_pipeline"] = total
-traffic["_source"] = f"profiles/{tag}_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+traffic["_source"] = (f"profiles/{tag}_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                      "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 FETCH_SIZE correction of "
+                      "/opt/skills/guides/MI355X_MICROARCH.md)")
 with open(tfile, "w") as f:
     json.dump(traffic, f, indent=1)
 print(json.dumps(summary, indent=1)[:3000])
