@@ -157,3 +157,23 @@ def test_long_sequence_folds_the_lazy_decay_mid_chunk(device, kind):
               grid_resolution=0.15)
     lay, ol = run_pair(kw, fr, device, kind=kind, iw=1.0)
     assert float(ol.data.max()) > 0.1
+
+
+@pytest.mark.parametrize("kind,C", [("label", 9), ("ones", 1), ("dense", 3)])
+def test_one_tile_takes_a_whole_frame(device, kind, C):
+    """A 120x160 frame whose points all fall into a 3x3x3-voxel corner of the map: one tile holds
+    more records than a work item of the single-pass kernel takes (it is cut into parts that merge
+    through global scratch), every voxel receives thousands of points (exact integer sums), and a
+    third of the points sit exactly on voxel boundaries (sub-unit corner weights)."""
+    h, w, n = 120, 160, 3
+    g = torch.Generator().manual_seed(21)
+    depth = 0.02 + 0.13 * torch.rand(n, h, w, 1, generator=g)
+    depth[:, ::3] = 0.1                                                    # many identical points
+    fr = dict(position=torch.tensor([[0.05, 0.05, 0.05]]).repeat(n, 1), yaw=torch.tensor([0.3, 1.2, 2.9]),
+              elevation=torch.tensor([-0.2, 0.1, -0.5]), depth=depth,
+              features=torch.rand(n, h, w, C, generator=g) - (0.3 if kind == "dense" else 0.0),
+              semantic=torch.randint(0, C, (n, h, w), generator=g))
+    kw = dict(camera_height=h, camera_width=w, map_height=16, map_width=16, map_depth=16, feature_size=C,
+              grid_resolution=0.1)
+    run_pair(kw, fr, device, kind=kind, batch=False)                       # three single-frame updates
+    run_pair(kw, fr, device, kind=kind, batch=True)                        # the same as one sequential batch
