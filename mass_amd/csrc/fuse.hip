@@ -409,7 +409,7 @@ __device__ __forceinline__ unsigned div_magic(unsigned n, unsigned magic)   // n
 // Visit the corners of point record r that fall inside the tile whose origin
 // is (o0, o1, o2): body(v, w) gets the tile-local voxel id and the corner weight.
 template <class F>
-__device__ __forceinline__ void for_corners(const TileParams &P, const uint4 &r, int o0, int o1, int o2, F body)
+__device__ __forceinline__ void for_corners_idx(const TileParams &P, const uint4 &r, int o0, int o1, int o2, F body)
 {
     const int k0 = r.x & 1023, k1 = (r.x >> 10) & 1023, k2 = (r.x >> 20) & 1023;
     const AxisFoot a0 = axis_foot(k0, __uint_as_float(r.y), P.size0);
@@ -434,9 +434,15 @@ __device__ __forceinline__ void for_corners(const TileParams &P, const uint4 &r,
         const int ca = cc >> 2, cb = (cc >> 1) & 1, cd = cc & 1;
         if (in0[ca] && in1[cb] && in2[cd]) {
             const float pw = w01[ca * 2 + cb] * w2[cd];
-            body((int)(p0[ca] | p1[cb] | p2[cd]), 1e-9f + pw);
+            body(cc, (int)(p0[ca] | p1[cb] | p2[cd]), 1e-9f + pw);
         }
     }
+}
+
+template <class F>
+__device__ __forceinline__ void for_corners(const TileParams &P, const uint4 &r, int o0, int o1, int o2, F body)
+{
+    for_corners_idx(P, r, o0, o1, o2, [&](int, int v, float w) { body(v, w); });
 }
 
 // Dev-only phase accounting (MF_STAMPS=1): cycles of workgroup-thread 0 between
@@ -445,7 +451,7 @@ __device__ unsigned long long g_stamps[8];
 #define MF_STAMP(i)                                                                   \
     if (STAMPS && tid == 0) {                                                         \
         const unsigned long long _t = __builtin_amdgcn_s_memtime();                   \
-        atomicAdd(&g_stamps[i], _t - t_last);                                         \
+        stamp_acc[i] += _t - t_last;                                                  \
         t_last = _t;                                                                  \
     }
 
@@ -518,6 +524,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 {
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};   // summed locally, written once at the end
     const int tid = threadIdx.x, NT = blockDim.x;
     const int C = P.C;
     const int sv = P.s0 + P.s1 + P.s2;
@@ -606,14 +613,19 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     __syncthreads();
     int buf = 0;
     // first EB entries per thread of the tile's first bucket range, fetched one tile ahead
+    // They stay in registers for the whole tile: a tile with at most NT * EB records (most tiles of
+    // a batch of unrelated frames) never goes back to global memory inside its chunk loop, whose
+    // phases are then LDS latency plus barriers only.
     uint4 pre[EB];
+    uint32_t prex[EB];
     auto prefetch_entries = [&](const int *o) {
         const int ta = o[0], tb = o[G];
 #pragma unroll
         for (int j = 0; j < EB; ++j) {
             const int e = ta + tid + j * NT;
             pre[j].x = 0xffffffffu;
-            if (e < tb) pre[j] = P.rec[e];
+            prex[j] = 0;
+            if (e < tb) { pre[j] = P.rec[e]; if (KIND == 1) prex[j] = P.aux[e]; }
         }
     };
     if (tile >= 0) prefetch_entries(offs2);
@@ -622,6 +634,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
         int onext[OPT];
         if (tile_next >= 0) load_offs(tile_next, onext);      // in flight during the first chunk
         const int *offs = offs2 + buf * (MAX_GROUPS + 1);
+        const int t_a = offs[0];
         MF_STAMP(0)
         const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
         const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
@@ -679,32 +692,32 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             auto slot_of = [&](int e) { int j = 0; for (int q = 1; q < nc; ++q) j += e >= cb[q]; return j; };
 
             // pass 1: W_f, S2_f.  Entries are taken EB at a time per thread, all EB loads issued
-            // before the first use (memory-level parallelism: one workgroup per CU).
-            for (int bb = ea; bb < eb; bb += NT * EB) {
+            // before the first use (memory-level parallelism: one workgroup per CU).  Batches are
+            // aligned to the tile's first record, so the first batch is always the register copy.
+            const int bb0 = t_a + (ea - t_a) / (NT * EB) * (NT * EB);
+            for (int bb = bb0; bb < eb; bb += NT * EB) {
                 uint4 r[EB];
-                if (c0 == 0 && bb == ea) {
+                if (bb == t_a) {
 #pragma unroll
-                    for (int j = 0; j < EB; ++j) {       // fetched while the previous tile was finishing
-                        r[j] = pre[j];
-                        if (bb + tid + j * NT >= eb) r[j].x = 0xffffffffu;
-                    }
+                    for (int j = 0; j < EB; ++j) r[j] = pre[j];
                 } else {
 #pragma unroll
                     for (int j = 0; j < EB; ++j) {
                         const int e = bb + tid + j * NT;
-                        r[j].x = 0xffffffffu;
-                        if (e < eb) r[j] = P.rec[e];
+                        if (e >= ea && e < eb) r[j] = P.rec[e];
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < EB; ++j)
-                    if (r[j].x != 0xffffffffu) {
-                        const int base = slot_of(bb + tid + j * NT) * TV;
+                for (int j = 0; j < EB; ++j) {
+                    const int e = bb + tid + j * NT;
+                    if (e >= ea && e < eb) {
+                        const int base = slot_of(e) * TV;
                         for_corners(P, r[j], o0, o1, o2, [&](int v, float w) {
                             atomicAdd(&W64[base + v], to_fixed(w, fx_c));
                             atomicAdd(&S64[base + v], to_fixed(w * w, fx_c));
                         });
                     }
+                }
             }
             if (c0 == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and everything older)
@@ -745,28 +758,58 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             MF_STAMP(4)
             // pass 3: D += k_f * w^2 * feat
             if (KIND == 0 || KIND == 1) {
+                // The adds of a record's corners are issued in rounds (all k reads, all reads of the
+                // current sums, all compare-and-swaps, then the float atomics of lanes that lost a race),
+                // four corners at a time: one LDS round trip per round instead of three per corner.
                 auto add = [&](int e, const uint4 &r, uint32_t label) {
+                    if (KIND == 1 && label >= (uint32_t)C) return;
                     const int base = slot_of(e) * TV;
-                    if (KIND == 0)
-                        for_corners(P, r, o0, o1, o2, [&](int v, float w) { lds_add_f32(&D[v], (w * w) * klow(W64, base + v)); });
-                    else if (label < (uint32_t)C)
-                        for_corners(P, r, o0, o1, o2, [&](int v, float w) {
-                            lds_add_f32(&D[v * C + label], (w * w) * klow(W64, base + v));
-                        });
+                    int vi[8];
+                    float q[8];
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
+                    for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; q[cc] = w * w; });
+                    unsigned *Du = reinterpret_cast<unsigned *>(D);
+#pragma unroll
+                    for (int h = 0; h < 8; h += 4) {
+                        unsigned seen[4], prev[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (vi[h + i] >= 0) q[h + i] *= klow(W64, base + vi[h + i]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (vi[h + i] >= 0) {
+                                vi[h + i] = KIND == 0 ? vi[h + i] : vi[h + i] * C + (int)label;
+                                seen[i] = Du[vi[h + i]];
+                            }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (vi[h + i] >= 0)
+                                prev[i] = atomicCAS(&Du[vi[h + i]], seen[i], __float_as_uint(__uint_as_float(seen[i]) + q[h + i]));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (vi[h + i] >= 0 && prev[i] != seen[i]) atomicAdd(&D[vi[h + i]], q[h + i]);
+                    }
                 };
-                for (int bb = ea; bb < eb; bb += NT * EB) {
+                for (int bb = bb0; bb < eb; bb += NT * EB) {
                     uint4 r[EB];
                     uint32_t x[EB];
+                    if (bb == t_a) {
+#pragma unroll
+                        for (int j = 0; j < EB; ++j) { r[j] = pre[j]; x[j] = prex[j]; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < EB; ++j) {
+                            const int e = bb + tid + j * NT;
+                            x[j] = 0;
+                            if (e >= ea && e < eb) { r[j] = P.rec[e]; if (KIND == 1) x[j] = P.aux[e]; }
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < EB; ++j) {
                         const int e = bb + tid + j * NT;
-                        r[j].x = 0xffffffffu;
-                        x[j] = 0;
-                        if (e < eb) { r[j] = P.rec[e]; if (KIND == 1) x[j] = P.aux[e]; }
+                        if (e >= ea && e < eb) add(e, r[j], x[j]);
                     }
-#pragma unroll
-                    for (int j = 0; j < EB; ++j)
-                        if (r[j].x != 0xffffffffu) add(bb + tid + j * NT, r[j], x[j]);
                 }
             } else {
                 // lanes-per-entry: the smallest power of two >= min(C, 64)
@@ -822,9 +865,9 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                 const unsigned v0 = div_magic(i, P.magicC), v3 = div_magic(i + 3, P.magicC);
                 const unsigned v1 = C < 3 ? div_magic(i + 1, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 1, P.magicC));
                 const unsigned v2 = C < 3 ? div_magic(i + 2, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 2, P.magicC));
-                if (touched[v0] | touched[v1] | touched[v2] | touched[v3]) {
-                    const unsigned r = v0 >> P.s2;                 // row = (l0, l1)
-                    const int l1 = r & m1, l0 = r >> P.s1;
+                const unsigned r = v0 >> P.s2;                 // row = (l0, l1)
+                const int l1 = r & m1, l0 = r >> P.s1;
+                if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
                     const size_t g = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len);
                     const float4 d = *reinterpret_cast<const float4 *>(D + i);
                     float4 o;
@@ -858,12 +901,17 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                     if (li[j] != 0xffffffffu) P.map[gi[j]] = osc[vv[j]] * old[j] + sc[vv[j]] * D[li[j]];
             }
         }
-        __syncthreads();
+        // the stores of the final pass drain while the next tile starts (its preload lands in D, whose
+        // values this pass already holds in registers); a full barrier here waits for every write to be
+        // acknowledged by memory
+        if (P.vec4) barrier_keep_vm(); else __syncthreads();
         MF_STAMP(6)
         tile = tile_next;
         tile_next = misc[2];
         buf ^= 1;
     }
+    if (STAMPS && tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], stamp_acc[i]);
 }
 
 // ----------------------------------------------------------------------------
@@ -910,6 +958,7 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
     extern __shared__ float smem[];
     const int tid = threadIdx.x;
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};   // summed locally, written once at the end
     const int C = P.C;
     const int sv = P.s0 + P.s1 + P.s2;
     const int TV = 1 << sv;
@@ -1102,6 +1151,8 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
         MF_STAMP(5)
         tile = tile_n; meta = meta_n; s = s_n; e = e_n;
     }
+    if (STAMPS && tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], stamp_acc[i]);
 }
 
 // max |x| over a dense feature image, as float bits in *out (non-negative floats order like their bits)
