@@ -349,6 +349,7 @@ __device__ __forceinline__ int tile_class(int n)
 // every non-empty tile, one with more than split_min records cut into `nparts` record ranges.
 constexpr int SPLIT_ITEMS = ABORT_SLOT + 1, SPLIT_TILES = ABORT_SLOT + 2, SPLIT_NONEMPTY = ABORT_SLOT + 3;
 constexpr int FEAT_ABSMAX = ABORT_SLOT + 4;     // bits of max |feature| of the call (dense single-pass path)
+constexpr int MODE_SLOT = ABORT_SLOT + 5;       // 1: the call's frames are sparse, fuse_sparse_kernel takes it (else fuse_tiles_kernel)
 constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
 constexpr int SPLIT_PARTS_MAX = 64;
@@ -357,10 +358,15 @@ constexpr long long SINGLE_MAX_POINTS = 1 << 21;   // calls with more points (a 
 __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
                                                         int n_tiles, int G, int *ticket, int *active,
                                                         int split_min, int split_part, int split_slots, int *items,
-                                                        int min_mean, int first_ticket)
+                                                        int min_mean, int first_ticket, int sparse_max_mean)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) ticket[0] = first_ticket;          // the tile kernel deals its first items statically (see there)
+    if (t == 0) {
+        ticket[0] = first_ticket;                   // the tile kernel deals its first items statically (see there)
+        // few records per non-empty (tile, frame) bucket on average: the sparse variant of the tile kernel
+        ticket[MODE_SLOT] = sparse_max_mean > 0 &&
+                            (long long)cursor[n_tiles * G] <= (long long)ticket[SPLIT_NONEMPTY] * sparse_max_mean;
+    }
     int n = 0;
     if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
     if (t < n_tiles) n = cursor[(t + 1) * G] - cursor[t * G];
@@ -586,6 +592,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     // wait (the old-map preload): nothing else is outstanding there, so reading the results of the
     // loads issued one tile earlier costs no wait of its own (vmcnt retires in order: waiting for an
     // old load at any other point would also wait for every younger load and store of the wave).
+    if (P.ticket[MODE_SLOT] == 1) return;                                        // fuse_sparse_kernel takes the call (uniform)
     if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;      // nothing listed (uniform)
     // The first four work items of a workgroup are dealt statically, list positions b, b + n, b + 2n,
     // b + 3n for workgroup b of n: the list is heaviest first, so every workgroup starts on one of the
@@ -758,38 +765,14 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             MF_STAMP(4)
             // pass 3: D += k_f * w^2 * feat
             if (KIND == 0 || KIND == 1) {
-                // The adds of a record's corners are issued in rounds (all k reads, all reads of the
-                // current sums, all compare-and-swaps, then the float atomics of lanes that lost a race),
-                // four corners at a time: one LDS round trip per round instead of three per corner.
                 auto add = [&](int e, const uint4 &r, uint32_t label) {
-                    if (KIND == 1 && label >= (uint32_t)C) return;
                     const int base = slot_of(e) * TV;
-                    int vi[8];
-                    float q[8];
-#pragma unroll
-                    for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
-                    for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; q[cc] = w * w; });
-                    unsigned *Du = reinterpret_cast<unsigned *>(D);
-#pragma unroll
-                    for (int h = 0; h < 8; h += 4) {
-                        unsigned seen[4], prev[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (vi[h + i] >= 0) q[h + i] *= klow(W64, base + vi[h + i]);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (vi[h + i] >= 0) {
-                                vi[h + i] = KIND == 0 ? vi[h + i] : vi[h + i] * C + (int)label;
-                                seen[i] = Du[vi[h + i]];
-                            }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (vi[h + i] >= 0)
-                                prev[i] = atomicCAS(&Du[vi[h + i]], seen[i], __float_as_uint(__uint_as_float(seen[i]) + q[h + i]));
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (vi[h + i] >= 0 && prev[i] != seen[i]) atomicAdd(&D[vi[h + i]], q[h + i]);
-                    }
+                    if (KIND == 0)
+                        for_corners(P, r, o0, o1, o2, [&](int v, float w) { lds_add_f32(&D[v], (w * w) * klow(W64, base + v)); });
+                    else if (label < (uint32_t)C)
+                        for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                            lds_add_f32(&D[v * C + label], (w * w) * klow(W64, base + v));
+                        });
                 };
                 for (int bb = bb0; bb < eb; bb += NT * EB) {
                     uint4 r[EB];
@@ -905,6 +888,400 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
         // values this pass already holds in registers); a full barrier here waits for every write to be
         // acknowledged by memory
         if (P.vec4) barrier_keep_vm(); else __syncthreads();
+        MF_STAMP(6)
+        tile = tile_next;
+        tile_next = misc[2];
+        buf ^= 1;
+    }
+    if (STAMPS && tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], stamp_acc[i]);
+}
+
+
+// ----------------------------------------------------------------------------
+// tile kernel for sparse frames
+// ----------------------------------------------------------------------------
+// A batch of unrelated frames (SURVEY 8(d) distribution A) leaves ~16 records per tile and frame:
+// the chunk phases of fuse_tiles_kernel are then latency (a barrier and two or three LDS round
+// trips each) with most lanes idle, and their number is what the tile costs.  This variant halves
+// the accumulator cell (W and S2 as a PAIR OF FLOATS in one 64-bit word, added with one 64-bit
+// compare-and-swap: cells of such frames are rarely contended) and uses the space for a second
+// buffer, so that two chunks are in flight:
+//     phase A(c):  pass 3 of chunk c (adds k * w^2 into D)   ||  pass 1 of chunk c+1 (W, S2)
+//     phase B(c):  zero the cells of chunk c                 ||  pass 2 of chunk c+1 (k per cell)
+// i.e. two barriers per chunk instead of four, each phase with two independent dependency chains.
+// Calls whose frames are dense (many records per tile and frame: compare-and-swap would spin)
+// stay with fuse_tiles_kernel; tile_list_kernel decides per call (ticket[MODE_SLOT]).
+constexpr int SPARSE_MAX_MEAN = 128;      // mean records per non-empty (tile, frame) bucket up to which a call is "sparse"
+
+__device__ __forceinline__ unsigned long long pack_ws(float w, float s2)
+{
+    return (unsigned long long)__float_as_uint(w) | ((unsigned long long)__float_as_uint(s2) << 32);
+}
+
+template <int KIND, int MAXT, bool STAMPS = false>
+__global__ __launch_bounds__(MAXT) void fuse_sparse_kernel(TileParams P)
+{
+    extern __shared__ float smem[];
+    unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int C = P.C;
+    const int sv = P.s0 + P.s1 + P.s2;
+    const int TV = 1 << sv;
+    const int GC = P.gc;
+    unsigned long long *A = reinterpret_cast<unsigned long long *>(smem);      // [2][GC][TV] (W | S2 << 32), low word = k after pass 2
+    float *D = reinterpret_cast<float *>(A + 2 * (size_t)GC * TV);             // [TV][C]
+    float *sc = D + (size_t)TV * C;                                            // [TV]
+    int *offs2 = (int *)(sc + TV);                                             // [2][MAX_GROUPS + 1]
+    int *cb2 = offs2 + 2 * (MAX_GROUPS + 1);                                   // [2][MAX_CHUNK + 1]
+    int *misc = cb2 + 2 * (MAX_CHUNK + 1);
+    unsigned short *ne = (unsigned short *)(misc + 8);                         // [MAX_GROUPS]
+    const int G = P.G;
+    const int m1 = (1 << P.s1) - 1;
+    const unsigned n_el = (unsigned)TV * (unsigned)C;
+
+    if (P.ticket[MODE_SLOT] != 1) return;                                      // fuse_tiles_kernel takes the call (uniform)
+    // work list, tickets and offsets: as in fuse_tiles_kernel
+    auto resolve = [&](int idx) {
+        int tile_id = -1;
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) {
+            const int cc = misc[4 + c];
+            if (tile_id < 0 && idx >= 0 && idx < cc) tile_id = P.active[c * P.n_tiles + idx];
+            idx -= cc;
+        }
+        return tile_id;
+    };
+    constexpr int OPT = (MAX_GROUPS + 1 + 63) / 64;
+    auto load_offs = [&](int t, int (&o)[OPT]) {
+        const int kb = t * G;
+#pragma unroll
+        for (int q = 0; q < OPT; ++q) {
+            const int g = tid + q * NT;
+            o[q] = (g <= G && kb + g > 0) ? P.cursor[kb + g - 1] : 0;
+        }
+    };
+    auto store_offs = [&](int *dst, const int (&o)[OPT]) {
+#pragma unroll
+        for (int q = 0; q < OPT; ++q) {
+            const int g = tid + q * NT;
+            if (g <= G) dst[g] = o[q];
+        }
+    };
+    if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;
+    int idx_pend = -1, act_pend = -1;
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) misc[4 + c] = P.ticket[1 + c];
+        const int nb = gridDim.x, b = blockIdx.x;
+        misc[0] = resolve(b);
+        misc[3] = resolve(b + nb);
+        act_pend = resolve(b + 2 * nb);
+        idx_pend = b + 3 * nb;
+    }
+    __syncthreads();
+    int tile = misc[0];
+    int tile_next = misc[3];
+    if (tile >= 0) {
+        int o[OPT];
+        load_offs(tile, o);
+        store_offs(offs2, o);
+    }
+    __syncthreads();
+    int buf = 0;
+    uint4 pre[EB];
+    uint32_t prex[EB];
+    auto prefetch_entries = [&](const int *o) {
+        const int ta = o[0], tb = o[G];
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            const int e = ta + tid + j * NT;
+            pre[j].x = 0xffffffffu;
+            prex[j] = 0;
+            if (e < tb) { pre[j] = P.rec[e]; if (KIND == 1) prex[j] = P.aux[e]; }
+        }
+    };
+    if (tile >= 0) prefetch_entries(offs2);
+
+    while (tile >= 0) {
+        int onext[OPT];
+        if (tile_next >= 0) load_offs(tile_next, onext);
+        const int *offs = offs2 + buf * (MAX_GROUPS + 1);
+        const int t_a = offs[0];
+        MF_STAMP(0)
+        const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
+        const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
+
+        // ---- setup: non-empty frames (wave 0, which also lays out chunk 0), old values -> D, s = 1, cells of chunk 0 = 0
+        if (tid < 64) {
+            int count = 0;
+            for (int b = 0; b < G; b += 64) {
+                const int g = b + tid;
+                const bool f = g < G && offs[g + 1] > offs[g];
+                const unsigned long long m = __ballot(f);
+                if (f) ne[count + __popcll(m & ((1ull << tid) - 1ull))] = (unsigned short)g;
+                count += __popcll(m);
+            }
+            const int nc0 = min(GC, count);
+            if (tid <= nc0 && nc0 > 0) cb2[tid] = tid < nc0 ? offs[ne[tid]] : offs[ne[nc0 - 1] + 1];
+            if (tid == 0) misc[1] = count;
+        }
+        {
+            const unsigned n4 = n_el >> 2, row_len = (unsigned)C << P.s2;
+            for (unsigned q0 = (unsigned)(tid & ~63); q0 < n4; q0 += NT) {
+                const unsigned q = q0 + (tid & 63);
+                if (q < n4) {
+                    const unsigned i = q << 2;
+                    const unsigned r = div_magic(i, P.magicC) >> P.s2;
+                    const int l1 = r & m1, l0 = r >> P.s1;
+                    if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
+                        const float *g = P.map + ((((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C +
+                                                  (i - r * row_len));
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)g,
+                            (__attribute__((address_space(3))) void *)(D + ((size_t)q0 << 2)), 16, 0, 0);
+                    }
+                }
+            }
+        }
+        for (int v = tid; v < TV; v += NT) sc[v] = 1.0f;
+        for (int i = tid; i < GC * TV; i += NT) A[i] = 0ull;
+        barrier_keep_vm();
+        MF_STAMP(1)
+        const int n_ne = misc[1];
+        const int n_chunks = (n_ne + GC - 1) / GC;
+        auto chunk_nc = [&](int c) { return min(GC, n_ne - c * GC); };
+        // entry offsets of chunk c's frames -> cb2[c & 1]
+        auto write_cb = [&](int c) {
+            if (c < n_chunks) {
+                const int nc = chunk_nc(c);
+                if (tid <= nc) cb2[(c & 1) * (MAX_CHUNK + 1) + tid] = tid < nc ? offs[ne[c * GC + tid]] : offs[ne[c * GC + nc - 1] + 1];
+            }
+        };
+        auto zero_cells = [&](int c) {                // the cells chunk c will use (its buffer: c & 1)
+            if (c < n_chunks) {
+                unsigned long long *Ab = A + (size_t)(c & 1) * GC * TV;
+                const int n = chunk_nc(c) * TV;
+                for (int i = tid; i < n; i += NT) Ab[i] = 0ull;
+            }
+        };
+        // pass 1 of chunk c: W, S2 of every (voxel, frame) cell
+        auto pass1 = [&](int c) {
+            const int *cbp = cb2 + (c & 1) * (MAX_CHUNK + 1);
+            const int nc = chunk_nc(c);
+            const int ea = cbp[0], eb = cbp[nc];
+            unsigned long long *Ab = A + (size_t)(c & 1) * GC * TV;
+            const int bb0 = t_a + (ea - t_a) / (NT * EB) * (NT * EB);
+            for (int bb = bb0; bb < eb; bb += NT * EB) {
+                uint4 r[EB];
+                if (bb == t_a) {
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) r[j] = pre[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) {
+                        const int e = bb + tid + j * NT;
+                        if (e >= ea && e < eb) r[j] = P.rec[e];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int e = bb + tid + j * NT;
+                    if (e >= ea && e < eb) {
+                        int slot = 0;
+                        for (int q = 1; q < nc; ++q) slot += e >= cbp[q];
+                        unsigned long long *cell = Ab + slot * TV;
+                        int vi[8];
+                        float wv[8];
+#pragma unroll
+                        for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
+                        for_corners_idx(P, r[j], o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; wv[cc] = w; });
+                        // No branches between the LDS operations of a record (the wait counters are only
+                        // tracked exactly inside a basic block): a corner outside the tile goes through the
+                        // motions on the cell of one that is inside, with a compare value no cell ever holds.
+                        int vf = 0;
+#pragma unroll
+                        for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
+#pragma unroll
+                        for (int h = 0; h < 8; h += 4) {
+                            unsigned long long seen[4], prev[4];
+                            int a[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                a[i] = vi[h + i] >= 0 ? vi[h + i] : vf;
+                                seen[i] = cell[a[i]];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float w = wv[h + i];
+                                const bool on = vi[h + i] >= 0;
+                                const unsigned long long nw = pack_ws(__uint_as_float((unsigned)seen[i]) + w,
+                                                                      __uint_as_float((unsigned)(seen[i] >> 32)) + w * w);
+                                prev[i] = atomicCAS(&cell[a[i]], on ? seen[i] : ~0ull, on ? nw : ~0ull);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (vi[h + i] >= 0) {
+                                    const float w = wv[h + i];
+                                    while (prev[i] != seen[i]) {        // lost a race: again on what is there now
+                                        seen[i] = prev[i];
+                                        prev[i] = atomicCAS(&cell[a[i]], seen[i],
+                                                            pack_ws(__uint_as_float((unsigned)seen[i]) + w,
+                                                                    __uint_as_float((unsigned)(seen[i] >> 32)) + w * w));
+                                    }
+                                }
+                        }
+                    }
+                }
+            }
+        };
+        // pass 2 of chunk c: per voxel, frames in order: s *= a_f, k_f = g_f / s
+        auto pass2 = [&](int c) {
+            const int nc = chunk_nc(c);
+            unsigned long long *Ab = A + (size_t)(c & 1) * GC * TV;
+            for (int v = tid; v < TV; v += NT) {
+                float s = sc[v];
+                bool any = false;
+                for (int j = 0; j < nc; ++j) {
+                    const unsigned long long cell = Ab[j * TV + v];
+                    if ((unsigned)cell != 0u) {
+                        const float Wv = __uint_as_float((unsigned)cell), S2 = __uint_as_float((unsigned)(cell >> 32));
+                        const float rW = __builtin_amdgcn_rcpf(Wv);
+                        const float a = 1.0f - P.iw * (S2 * rW);
+                        s *= a;
+                        if (!(s >= RESCALE_BELOW)) {
+                            for (int ch = 0; ch < C; ++ch) D[v * C + ch] *= s;
+                            for (int t = 0; t < j; ++t) reinterpret_cast<float *>(&Ab[t * TV + v])[0] *= s;
+                            s = 1.0f;
+                        }
+                        reinterpret_cast<float *>(&Ab[j * TV + v])[0] = P.iw * rW * __builtin_amdgcn_rcpf(s);
+                        any = true;
+                    }
+                }
+                if (any) sc[v] = s;
+            }
+        };
+        // pass 3 of chunk c: D += k_f * w^2 * feat (rounds of four corners, see fuse_tiles_kernel)
+        auto pass3 = [&](int c) {
+            const int *cbp = cb2 + (c & 1) * (MAX_CHUNK + 1);
+            const int nc = chunk_nc(c);
+            const int ea = cbp[0], eb = cbp[nc];
+            const unsigned long long *Ab = A + (size_t)(c & 1) * GC * TV;
+            unsigned *Du = reinterpret_cast<unsigned *>(D);
+            const int bb0 = t_a + (ea - t_a) / (NT * EB) * (NT * EB);
+            for (int bb = bb0; bb < eb; bb += NT * EB) {
+                uint4 r[EB];
+                uint32_t x[EB];
+                if (bb == t_a) {
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) { r[j] = pre[j]; x[j] = prex[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) {
+                        const int e = bb + tid + j * NT;
+                        x[j] = 0;
+                        if (e >= ea && e < eb) { r[j] = P.rec[e]; if (KIND == 1) x[j] = P.aux[e]; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int e = bb + tid + j * NT;
+                    if (e >= ea && e < eb && (KIND == 0 || x[j] < (uint32_t)C)) {
+                        int slot = 0;
+                        for (int q = 1; q < nc; ++q) slot += e >= cbp[q];
+                        const int base = slot * TV;
+                        int vi[8];
+                        float qv[8];
+#pragma unroll
+                        for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
+                        for_corners_idx(P, r[j], o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+                        int vf = 0;
+#pragma unroll
+                        for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
+#pragma unroll
+                        for (int h = 0; h < 8; h += 4) {                 // branch-free rounds, as in pass 1
+                            unsigned seen[4], prev[4];
+                            int a[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                a[i] = vi[h + i] >= 0 ? vi[h + i] : vf;
+                                qv[h + i] *= klow(Ab, base + a[i]);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                a[i] = KIND == 0 ? a[i] : a[i] * C + (int)x[j];
+                                seen[i] = Du[a[i]];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const bool on = vi[h + i] >= 0;
+                                prev[i] = atomicCAS(&Du[a[i]], on ? seen[i] : 0xffffffffu,
+                                                    on ? __float_as_uint(__uint_as_float(seen[i]) + qv[h + i]) : 0xffffffffu);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (vi[h + i] >= 0 && prev[i] != seen[i]) atomicAdd(&D[a[i]], qv[h + i]);
+                        }
+                    }
+                }
+            }
+        };
+
+        // ---- prologue: pass 1 and pass 2 of chunk 0
+        pass1(0);
+        zero_cells(1);
+        write_cb(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the preload
+        if (tid == 0) {                                              // advance the ticket pipeline (see fuse_tiles_kernel)
+            misc[2] = act_pend;
+            act_pend = resolve(idx_pend);
+            idx_pend = atomicAdd(P.ticket, 1);
+        }
+        barrier_keep_vm();
+        MF_STAMP(2)
+        pass2(0);
+        barrier_keep_vm();
+        MF_STAMP(3)
+        for (int c = 0; c < n_chunks; ++c) {
+            pass3(c);
+            if (c + 1 < n_chunks) pass1(c + 1);
+            if (c == 0 && tile_next >= 0) store_offs(offs2 + (buf ^ 1) * (MAX_GROUPS + 1), onext);
+            if (c + 1 == n_chunks) break;
+            barrier_keep_vm();
+            MF_STAMP(4)
+            zero_cells(c + 2);
+            pass2(c + 1);
+            write_cb(c + 2);
+            barrier_keep_vm();
+            MF_STAMP(5)
+        }
+        if (tile_next >= 0) prefetch_entries(offs2 + (buf ^ 1) * (MAX_GROUPS + 1));   // lands during the final pass
+        barrier_keep_vm();
+        MF_STAMP(4)
+
+        // ---- final pass: every row of the tile is written as s * D (untouched voxels: s = 1, D = old value)
+        {
+            const unsigned row_len = (unsigned)C << P.s2;
+            const unsigned n4 = n_el >> 2;
+            float4 *map4w = reinterpret_cast<float4 *>(P.map);
+            for (unsigned q = tid; q < n4; q += NT) {
+                const unsigned i = q << 2;
+                const unsigned v0 = div_magic(i, P.magicC), v3 = div_magic(i + 3, P.magicC);
+                const unsigned v1 = C < 3 ? div_magic(i + 1, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 1, P.magicC));
+                const unsigned v2 = C < 3 ? div_magic(i + 2, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 2, P.magicC));
+                const unsigned r = v0 >> P.s2;
+                const int l1 = r & m1, l0 = r >> P.s1;
+                if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
+                    const size_t g = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len);
+                    const float4 d = *reinterpret_cast<const float4 *>(D + i);
+                    float4 o;
+                    o.x = sc[v0] * d.x; o.y = sc[v1] * d.y; o.z = sc[v2] * d.z; o.w = sc[v3] * d.w;
+                    map4w[g >> 2] = o;
+                }
+            }
+        }
+        barrier_keep_vm();
         MF_STAMP(6)
         tile = tile_next;
         tile_next = misc[2];
@@ -1424,6 +1801,28 @@ static size_t tile_lds_bytes(int C, int sv, int gc)
     return tile_lds_fixed(C, sv) + (size_t)gc * ((size_t)1 << sv) * 16;
 }
 
+// fuse_sparse_kernel: deltas, s, two offset arrays, two chunk layouts, misc, non-empty list; per chunk frame
+// two buffers of 8-byte cells
+static size_t sparse_lds_fixed(int C, int sv)
+{
+    const size_t TV = (size_t)1 << sv;
+    return TV * C * 4 + TV * 4 + 2 * (MAX_GROUPS + 1) * 4 + 2 * (MAX_CHUNK + 1) * 4 + 8 * 4 + MAX_GROUPS * 2 + 16;
+}
+
+static int sparse_chunk_frames(int C, int sv, int G)
+{
+    const size_t per_slot = ((size_t)1 << sv) * 16;
+    const size_t fixed = sparse_lds_fixed(C, sv);
+    size_t avail = fixed + per_slot <= 160 * 1024 ? 160 * 1024 - fixed : per_slot;
+    if (avail > 64 * 1024) avail = 64 * 1024;
+    int gc = (int)(avail / per_slot);
+    if (g_gc_override > 0) gc = g_gc_override;
+    if (gc > MAX_CHUNK) gc = MAX_CHUNK;
+    if (gc > G) gc = G;
+    if (gc < 1) gc = 1;
+    return gc;
+}
+
 struct Layout {
     size_t cursor, block_sums, ticket, slot_count, slot_ws, slot_u, slot_bits, active, items, rec, aux, total;
     int n_keys, n_scan_blocks;
@@ -1618,7 +2017,16 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
     int blocks = dev.cus * per_cu;
+    { static const int cap = getenv("MF_BLOCKS") ? atoi(getenv("MF_BLOCKS")) : 0; if (cap > 0 && blocks > cap) blocks = cap; }   // dev: fewer workgroups
     if (blocks > P.n_tiles) blocks = P.n_tiles;
+    // sparse variant of the tile kernel (class ids / ones, several sequential frames, float4 rows): offered to
+    // the call when it would run with the same grid; tile_list_kernel decides on the device which of the two runs
+    static const bool sparse_on = !(getenv("MF_SPARSE") && atoi(getenv("MF_SPARSE")) == 0);
+    int sgc = sparse_chunk_frames(P.C, sv, P.G);
+    if (phase != 3 && sgc > 2) sgc -= 1;
+    const size_t slds_sparse = sparse_lds_fixed(P.C, sv) + (size_t)sgc * ((size_t)16 << sv);
+    const bool sparse = sparse_on && P.feat_kind != MF_FEAT_DENSE_F32 && P.vec4 && P.G > 1 && nt >= 64 &&
+                        slds_sparse <= (size_t)dev.lds_per_cu && (int)((size_t)dev.lds_per_cu / slds_sparse) >= per_cu;
 
     if (phase & 1) {
     prof_mark(0, st);
@@ -1637,11 +2045,12 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
                        (const int *)P.cursor, P.n_keys + 1, P.block_sums);
     MF_LAUNCH_CHECK("scan_sums_kernel");
     hipLaunchKernelGGL(scan_apply_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
-                       P.cursor, P.n_keys + 1, (const int *)P.block_sums, single ? P.ticket + SPLIT_NONEMPTY : (int *)nullptr);
+                       P.cursor, P.n_keys + 1, (const int *)P.block_sums, P.ticket + SPLIT_NONEMPTY);
     MF_LAUNCH_CHECK("scan_apply_kernel");
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
                        P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
-                       (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks);
+                       (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks,
+                       sparse ? SPARSE_MAX_MEAN : 0);
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
@@ -1686,6 +2095,27 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);      // returns at once when the call went to the single-pass kernel
     MF_LAUNCH_CHECK("fuse_tiles_kernel");
+    if (sparse) {
+        void (*sk)(TileParams);
+        if (nt <= 64) sk = kind == 0 ? fuse_sparse_kernel<0, 64> : fuse_sparse_kernel<1, 64>;
+        else if (nt <= 256) sk = kind == 0 ? fuse_sparse_kernel<0, 256> : fuse_sparse_kernel<1, 256>;
+        else sk = kind == 0 ? fuse_sparse_kernel<0, 1024> : fuse_sparse_kernel<1, 1024>;
+        if (stamps && nt > 256) sk = kind == 0 ? fuse_sparse_kernel<0, 1024, true> : fuse_sparse_kernel<1, 1024, true>;
+        {
+            static std::mutex mu3;
+            static std::unordered_map<const void *, size_t> granted3;
+            std::lock_guard<std::mutex> lock(mu3);
+            size_t &have = granted3[(const void *)sk];
+            if (have < slds_sparse) {
+                MF_HIP_CHECK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds_sparse));
+                have = slds_sparse;
+            }
+        }
+        TileParams S = T;
+        S.gc = sgc;
+        hipLaunchKernelGGL(sk, dim3(blocks), dim3(nt), slds_sparse, st, S);   // returns at once unless tile_list_kernel chose it
+        MF_LAUNCH_CHECK("fuse_sparse_kernel");
+    }
     if (single) {
         SingleParams S;
         S.size0 = P.size0; S.size1 = P.size1; S.size2 = P.size2; S.C = P.C; S.map = P.map; S.iw = P.iw;
