@@ -265,6 +265,10 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
         uint4 r;
         r.x = (uint32_t)pt.k0 | ((uint32_t)pt.k1 << 10) | ((uint32_t)pt.k2 << 20);
         r.y = __float_as_uint(pt.r0); r.z = __float_as_uint(pt.r1); r.w = __float_as_uint(pt.r2);
+        // the group (frame) rides in the two top bits of the four words: 10 + 10 + 10 index bits leave two,
+        // and a ratio in [0, 1] has its sign and top exponent bit clear (MAX_GROUPS = 256 = 8 bits)
+        const uint32_t g = (uint32_t)pt.group;
+        r.x |= (g & 3u) << 30; r.y |= ((g >> 2) & 3u) << 30; r.z |= ((g >> 4) & 3u) << 30; r.w |= ((g >> 6) & 3u) << 30;
         for (int i = 0; i < n; ++i) {
             const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
             P.rec[pos] = r;
@@ -358,14 +362,16 @@ constexpr long long SINGLE_MAX_POINTS = 1 << 21;   // calls with more points (a 
 __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
                                                         int n_tiles, int G, int *ticket, int *active,
                                                         int split_min, int split_part, int split_slots, int *items,
-                                                        int min_mean, int first_ticket, int sparse_max_mean)
+                                                        int min_mean, int first_ticket, int sparse_max_mean,
+                                                        int first_ticket_sparse)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
-        ticket[0] = first_ticket;                   // the tile kernel deals its first items statically (see there)
         // few records per non-empty (tile, frame) bucket on average: the sparse variant of the tile kernel
-        ticket[MODE_SLOT] = sparse_max_mean > 0 &&
+        const bool sparse = sparse_max_mean > 0 &&
                             (long long)cursor[n_tiles * G] <= (long long)ticket[SPLIT_NONEMPTY] * sparse_max_mean;
+        ticket[MODE_SLOT] = sparse;
+        ticket[0] = sparse ? first_ticket_sparse : first_ticket;   // the tile kernels deal their first items statically (see there)
     }
     int n = 0;
     if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
@@ -414,13 +420,22 @@ __device__ __forceinline__ unsigned div_magic(unsigned n, unsigned magic)   // n
 
 // Visit the corners of point record r that fall inside the tile whose origin
 // is (o0, o1, o2): body(v, w) gets the tile-local voxel id and the corner weight.
+// Sequential group (frame) of a record: eight spare bits of the record (scatter_kernel).
+__device__ __forceinline__ int rec_group(const uint4 &r)
+{
+    return (int)((r.x >> 30) | ((r.y >> 30) << 2) | ((r.z >> 30) << 4) | ((r.w >> 30) << 6));
+}
+
 template <class F>
 __device__ __forceinline__ void for_corners_idx(const TileParams &P, const uint4 &r, int o0, int o1, int o2, F body)
 {
     const int k0 = r.x & 1023, k1 = (r.x >> 10) & 1023, k2 = (r.x >> 20) & 1023;
-    const AxisFoot a0 = axis_foot(k0, __uint_as_float(r.y), P.size0);
-    const AxisFoot a1 = axis_foot(k1, __uint_as_float(r.z), P.size1);
-    const AxisFoot a2 = axis_foot(k2, __uint_as_float(r.w), P.size2);
+    // with several groups the top two bits of each ratio word carry the record's group (ratios of binned
+    // pixels lie in [0, 1]: sign and top exponent bit are 0); ratios handed in by a caller are taken as they are
+    const unsigned rm = P.G > 1 ? 0x3fffffffu : 0xffffffffu;
+    const AxisFoot a0 = axis_foot(k0, __uint_as_float(r.y & rm), P.size0);
+    const AxisFoot a1 = axis_foot(k1, __uint_as_float(r.z & rm), P.size1);
+    const AxisFoot a2 = axis_foot(k2, __uint_as_float(r.w & rm), P.size2);
     // per axis: tile-local coordinate of the lower / upper corner, pre-shifted into its field of
     // the local voxel id, and whether it lies inside the tile
     const unsigned l0 = (unsigned)(a0.lo - o0), h0 = (unsigned)(a0.hi - o0);
@@ -901,18 +916,29 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 // ----------------------------------------------------------------------------
 // tile kernel for sparse frames
 // ----------------------------------------------------------------------------
-// A batch of unrelated frames (SURVEY 8(d) distribution A) leaves ~16 records per tile and frame:
-// the chunk phases of fuse_tiles_kernel are then latency (a barrier and two or three LDS round
-// trips each) with most lanes idle, and their number is what the tile costs.  This variant halves
-// the accumulator cell (W and S2 as a PAIR OF FLOATS in one 64-bit word, added with one 64-bit
-// compare-and-swap: cells of such frames are rarely contended) and uses the space for a second
-// buffer, so that two chunks are in flight:
-//     phase A(c):  pass 3 of chunk c (adds k * w^2 into D)   ||  pass 1 of chunk c+1 (W, S2)
-//     phase B(c):  zero the cells of chunk c                 ||  pass 2 of chunk c+1 (k per cell)
-// i.e. two barriers per chunk instead of four, each phase with two independent dependency chains.
-// Calls whose frames are dense (many records per tile and frame: compare-and-swap would spin)
-// stay with fuse_tiles_kernel; tile_list_kernel decides per call (ticket[MODE_SLOT]).
+// A batch of unrelated frames (SURVEY 8(d) distribution A) leaves ~16 records per 8 x 8 x 8 tile and
+// frame.  fuse_tiles_kernel then spends its time in chunk phases that are a barrier plus two or three
+// LDS round trips each with most lanes idle, and one workgroup per CU alternates between moving
+// the tile (a CU on its own streams ~25 GB/s) and computing on it.  This variant is built the other
+// way round, on 4 x 4 x 8 tiles:
+//   * ALL frames of the call are one chunk: 64 frames x 128 voxels of 16-byte cells (W, S2 as 64-bit
+//     fixed point: integer LDS atomics need no return value, so pass 1 has no latency chain; a pair
+//     of floats updated by 64-bit compare-and-swap was 2.5x slower, the records of a frame sit in
+//     the same wave and collide) are 129 KB, and a tile costs four barriers in all; a 64-bit mask
+//     per voxel remembers the frames that touched it, so that pass 2 and the clearing of the cells
+//     visit only those (a quarter of the cells);
+//   * the frame of a record travels in the record (spare bits, see scatter_kernel): no per-tile
+//     offset table, no search;
+//   * the unrolled blend is written with SUFFIX products: m_n = (prod_f a_f) m_0 + sum_f t_f U_f,
+//     t_f = g_f * prod_{f' > f} a_f'  -- no division by a running scale, nothing to rescale;
+//   * the next tile's map values are fetched into registers while this tile is computed (512 threads:
+//     256 VGPRs each) and swapped into D as this tile's rows are stored, so the CU streams all the
+//     time.  (LDS-DMA is not used here: after a global_load_lds the compiler makes every later LDS
+//     read of the same array wait for vmcnt(0), which would serialise exactly what is to overlap.)
+// Calls whose frames are dense (long tiles; pass 3 adds floats by compare-and-swap) stay with fuse_tiles_kernel;
+// tile_list_kernel decides per call (ticket[MODE_SLOT]).
 constexpr int SPARSE_MAX_MEAN = 128;      // mean records per non-empty (tile, frame) bucket up to which a call is "sparse"
+constexpr int SPARSE_MAX_GC = 64;         // frames of a call (= cells per voxel)
 
 __device__ __forceinline__ unsigned long long pack_ws(float w, float s2)
 {
@@ -928,22 +954,21 @@ __global__ __launch_bounds__(MAXT) void fuse_sparse_kernel(TileParams P)
     const int tid = threadIdx.x, NT = blockDim.x;
     const int C = P.C;
     const int sv = P.s0 + P.s1 + P.s2;
-    const int TV = 1 << sv;
-    const int GC = P.gc;
-    unsigned long long *A = reinterpret_cast<unsigned long long *>(smem);      // [2][GC][TV] (W | S2 << 32), low word = k after pass 2
-    float *D = reinterpret_cast<float *>(A + 2 * (size_t)GC * TV);             // [TV][C]
-    float *sc = D + (size_t)TV * C;                                            // [TV]
-    int *offs2 = (int *)(sc + TV);                                             // [2][MAX_GROUPS + 1]
-    int *cb2 = offs2 + 2 * (MAX_GROUPS + 1);                                   // [2][MAX_CHUNK + 1]
-    int *misc = cb2 + 2 * (MAX_CHUNK + 1);
-    unsigned short *ne = (unsigned short *)(misc + 8);                         // [MAX_GROUPS]
+    const int TV = 1 << sv, TVP = TV + 1;          // cell rows are padded by one: pass 2 reads them strided by frames
     const int G = P.G;
     const int m1 = (1 << P.s1) - 1;
     const unsigned n_el = (unsigned)TV * (unsigned)C;
+    unsigned long long *A = reinterpret_cast<unsigned long long *>(smem);      // [G][TV + 1][2] W, S2; low word of W = t_f after pass 2
+    unsigned long long *mask = A + (size_t)G * TVP * 2;                        // [TV] frames that touched the voxel
+    float *Dc = reinterpret_cast<float *>(mask + TV);                          // [TV][C] the tile: old values, then the result
+    const int fx_c = 182 - P.fx_shift;
+    const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
+    int *misc = reinterpret_cast<int *>(Dc + (size_t)n_el);                    // [0..2] tile, first record, end; [4..7] class sizes; [8..10] next tile
 
     if (P.ticket[MODE_SLOT] != 1) return;                                      // fuse_tiles_kernel takes the call (uniform)
-    // work list, tickets and offsets: as in fuse_tiles_kernel
-    auto resolve = [&](int idx) {
+    if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;
+
+    auto resolve = [&](int idx) {          // work list position -> tile id, -1 past the end
         int tile_id = -1;
 #pragma unroll
         for (int c = 0; c < TILE_CLASSES; ++c) {
@@ -953,342 +978,271 @@ __global__ __launch_bounds__(MAXT) void fuse_sparse_kernel(TileParams P)
         }
         return tile_id;
     };
-    constexpr int OPT = (MAX_GROUPS + 1 + 63) / 64;
-    auto load_offs = [&](int t, int (&o)[OPT]) {
-        const int kb = t * G;
-#pragma unroll
-        for (int q = 0; q < OPT; ++q) {
-            const int g = tid + q * NT;
-            o[q] = (g <= G && kb + g > 0) ? P.cursor[kb + g - 1] : 0;
-        }
+    // The look-ups a tile needs (ticket -> list entry -> record range: three dependent global round
+    // trips) are made by thread 0 several tiles ahead, each advanced once per tile right after the
+    // workgroup's vmcnt(0) point.  The first four list positions of a workgroup are dealt statically
+    // (b, b + n, b + 2n, b + 3n: the list is heaviest first), tickets start at 4n.
+    int idx_pend = -1, act_pend = -1, rng_tile = -1, rng_s = 0, rng_e = 0, nx_tile = -1, nx_s = 0, nx_e = 0;
+    auto range_of = [&](int t, int &s, int &e) {
+        s = 0; e = 0;
+        if (t >= 0) { s = t * G > 0 ? P.cursor[t * G - 1] : 0; e = P.cursor[(t + 1) * G - 1]; }
     };
-    auto store_offs = [&](int *dst, const int (&o)[OPT]) {
-#pragma unroll
-        for (int q = 0; q < OPT; ++q) {
-            const int g = tid + q * NT;
-            if (g <= G) dst[g] = o[q];
-        }
-    };
-    if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;
-    int idx_pend = -1, act_pend = -1;
     if (tid == 0) {
 #pragma unroll
         for (int c = 0; c < TILE_CLASSES; ++c) misc[4 + c] = P.ticket[1 + c];
         const int nb = gridDim.x, b = blockIdx.x;
-        misc[0] = resolve(b);
-        misc[3] = resolve(b + nb);
-        act_pend = resolve(b + 2 * nb);
-        idx_pend = b + 3 * nb;
+        const int t0 = resolve(b);
+        int s0, e0;
+        range_of(t0, s0, e0);
+        misc[0] = t0; misc[1] = s0; misc[2] = e0;
+        nx_tile = resolve(b + nb);
+        range_of(nx_tile, nx_s, nx_e);
+        rng_tile = resolve(b + 2 * nb);
+        range_of(rng_tile, rng_s, rng_e);
+        act_pend = resolve(b + 3 * nb);
+        idx_pend = atomicAdd(P.ticket, 1);
     }
     __syncthreads();
-    int tile = misc[0];
-    int tile_next = misc[3];
-    if (tile >= 0) {
-        int o[OPT];
-        load_offs(tile, o);
-        store_offs(offs2, o);
-    }
-    __syncthreads();
-    int buf = 0;
-    uint4 pre[EB];
-    uint32_t prex[EB];
-    auto prefetch_entries = [&](const int *o) {
-        const int ta = o[0], tb = o[G];
+    int tile = misc[0], ts = misc[1], te = misc[2];
+    if (tile < 0) return;
+
+    uint4 pre[EB], pre_n[EB];
+    uint32_t prex[EB], prex_n[EB];
+    auto prefetch_entries = [&](int ta, int tb, uint4 (&q)[EB], uint32_t (&qx)[EB]) {
 #pragma unroll
-        for (int j = 0; j < EB; ++j) {
-            const int e = ta + tid + j * NT;
-            pre[j].x = 0xffffffffu;
-            prex[j] = 0;
-            if (e < tb) { pre[j] = P.rec[e]; if (KIND == 1) prex[j] = P.aux[e]; }
+        for (int j = 0; j < EB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
+            const int e = min(ta + tid + j * NT, tb - 1);
+            q[j] = P.rec[e];
+            qx[j] = KIND == 1 ? P.aux[e] : 0u;
         }
     };
-    if (tile >= 0) prefetch_entries(offs2);
+    auto tile_origin = [&](int t, int &o0, int &o1, int &o2) {
+        const int tz = t % P.nt2, ty = (t / P.nt2) % P.nt1, tx = t / (P.nt2 * P.nt1);
+        o0 = tx << P.s0; o1 = ty << P.s1; o2 = tz << P.s2;
+    };
+    // Thread `tid` owns the float4s tid, tid + NT, ... of the tile image: it fetches the tile's current
+    // values into registers a tile ahead, and at the end of a tile stores the result from D and puts the
+    // next tile's values in its place (its own elements only: no barrier in between).
+    constexpr int OVM = 4;                                  // float4s per thread (the host checks TV * C / 4 <= OVM * 512)
+    const unsigned n4 = n_el >> 2, row_len = (unsigned)C << P.s2;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f *map4 = reinterpret_cast<v4f *>(P.map);
+    auto elem_index = [&](int t, unsigned q, size_t &g4) {  // float4 q of tile t -> float4 index in the map, false outside the map
+        int o0, o1, o2;
+        tile_origin(t, o0, o1, o2);
+        const unsigned i = q << 2;
+        const unsigned r = div_magic(i, P.magicC) >> P.s2;
+        const int l1 = r & m1, l0 = r >> P.s1;
+        g4 = ((((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len)) >> 2;
+        return q < n4 && o0 + l0 < P.size0 && o1 + l1 < P.size1;
+    };
+    v4f oldv[OVM];
+    // all loads unconditional (an element outside the map reads element 0 and is never used): loads under
+    // separate branches would each wait for the one before
+#define MF_FETCH_OLD(t)                                                                    \
+    _Pragma("unroll") for (int j = 0; j < OVM; ++j) {                                      \
+        size_t g4;                                                                         \
+        const bool in = elem_index(t, tid + j * NT, g4);                                   \
+        oldv[j] = map4[in ? g4 : 0];                                                       \
+    }
 
-    while (tile >= 0) {
-        int onext[OPT];
-        if (tile_next >= 0) load_offs(tile_next, onext);
-        const int *offs = offs2 + buf * (MAX_GROUPS + 1);
-        const int t_a = offs[0];
+    prefetch_entries(ts, te, pre, prex);
+    MF_FETCH_OLD(tile)
+#pragma unroll
+    for (int j = 0; j < OVM; ++j) {
+        size_t g4;
+        if (elem_index(tile, tid + j * NT, g4)) reinterpret_cast<v4f *>(Dc)[tid + j * NT] = oldv[j];
+    }
+    for (int i = tid; i < G * TVP * 2 + TV; i += NT) A[i] = 0ull;            // cells and masks (later: only what a tile touched)
+    // threads of a voxel in pass 2: PP consecutive lanes, each with FP consecutive frames
+    const int PP = NT >> sv > 0 ? NT >> sv : 1;
+    const int FP = (G + PP - 1) / PP;
+
+    while (true) {
+        int o0, o1, o2;
+        tile_origin(tile, o0, o1, o2);
         MF_STAMP(0)
-        const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
-        const int o0 = tx << P.s0, o1 = ty << P.s1, o2 = tz << P.s2;
-
-        // ---- setup: non-empty frames (wave 0, which also lays out chunk 0), old values -> D, s = 1, cells of chunk 0 = 0
-        if (tid < 64) {
-            int count = 0;
-            for (int b = 0; b < G; b += 64) {
-                const int g = b + tid;
-                const bool f = g < G && offs[g + 1] > offs[g];
-                const unsigned long long m = __ballot(f);
-                if (f) ne[count + __popcll(m & ((1ull << tid) - 1ull))] = (unsigned short)g;
-                count += __popcll(m);
-            }
-            const int nc0 = min(GC, count);
-            if (tid <= nc0 && nc0 > 0) cb2[tid] = tid < nc0 ? offs[ne[tid]] : offs[ne[nc0 - 1] + 1];
-            if (tid == 0) misc[1] = count;
-        }
-        {
-            const unsigned n4 = n_el >> 2, row_len = (unsigned)C << P.s2;
-            for (unsigned q0 = (unsigned)(tid & ~63); q0 < n4; q0 += NT) {
-                const unsigned q = q0 + (tid & 63);
-                if (q < n4) {
-                    const unsigned i = q << 2;
-                    const unsigned r = div_magic(i, P.magicC) >> P.s2;
-                    const int l1 = r & m1, l0 = r >> P.s1;
-                    if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
-                        const float *g = P.map + ((((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C +
-                                                  (i - r * row_len));
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void *)g,
-                            (__attribute__((address_space(3))) void *)(D + ((size_t)q0 << 2)), 16, 0, 0);
-                    }
-                }
-            }
-        }
-        for (int v = tid; v < TV; v += NT) sc[v] = 1.0f;
-        for (int i = tid; i < GC * TV; i += NT) A[i] = 0ull;
-        barrier_keep_vm();
+        barrier_keep_vm();                                // cells and masks are clear, D holds the tile's values
         MF_STAMP(1)
-        const int n_ne = misc[1];
-        const int n_chunks = (n_ne + GC - 1) / GC;
-        auto chunk_nc = [&](int c) { return min(GC, n_ne - c * GC); };
-        // entry offsets of chunk c's frames -> cb2[c & 1]
-        auto write_cb = [&](int c) {
-            if (c < n_chunks) {
-                const int nc = chunk_nc(c);
-                if (tid <= nc) cb2[(c & 1) * (MAX_CHUNK + 1) + tid] = tid < nc ? offs[ne[c * GC + tid]] : offs[ne[c * GC + nc - 1] + 1];
-            }
-        };
-        auto zero_cells = [&](int c) {                // the cells chunk c will use (its buffer: c & 1)
-            if (c < n_chunks) {
-                unsigned long long *Ab = A + (size_t)(c & 1) * GC * TV;
-                const int n = chunk_nc(c) * TV;
-                for (int i = tid; i < n; i += NT) Ab[i] = 0ull;
-            }
-        };
-        // pass 1 of chunk c: W, S2 of every (voxel, frame) cell
-        auto pass1 = [&](int c) {
-            const int *cbp = cb2 + (c & 1) * (MAX_CHUNK + 1);
-            const int nc = chunk_nc(c);
-            const int ea = cbp[0], eb = cbp[nc];
-            unsigned long long *Ab = A + (size_t)(c & 1) * GC * TV;
-            const int bb0 = t_a + (ea - t_a) / (NT * EB) * (NT * EB);
-            for (int bb = bb0; bb < eb; bb += NT * EB) {
-                uint4 r[EB];
-                if (bb == t_a) {
-#pragma unroll
-                    for (int j = 0; j < EB; ++j) r[j] = pre[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < EB; ++j) {
-                        const int e = bb + tid + j * NT;
-                        if (e >= ea && e < eb) r[j] = P.rec[e];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < EB; ++j) {
-                    const int e = bb + tid + j * NT;
-                    if (e >= ea && e < eb) {
-                        int slot = 0;
-                        for (int q = 1; q < nc; ++q) slot += e >= cbp[q];
-                        unsigned long long *cell = Ab + slot * TV;
-                        int vi[8];
-                        float wv[8];
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
-                        for_corners_idx(P, r[j], o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; wv[cc] = w; });
-                        // No branches between the LDS operations of a record (the wait counters are only
-                        // tracked exactly inside a basic block): a corner outside the tile goes through the
-                        // motions on the cell of one that is inside, with a compare value no cell ever holds.
-                        int vf = 0;
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
-#pragma unroll
-                        for (int h = 0; h < 8; h += 4) {
-                            unsigned long long seen[4], prev[4];
-                            int a[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                a[i] = vi[h + i] >= 0 ? vi[h + i] : vf;
-                                seen[i] = cell[a[i]];
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float w = wv[h + i];
-                                const bool on = vi[h + i] >= 0;
-                                const unsigned long long nw = pack_ws(__uint_as_float((unsigned)seen[i]) + w,
-                                                                      __uint_as_float((unsigned)(seen[i] >> 32)) + w * w);
-                                prev[i] = atomicCAS(&cell[a[i]], on ? seen[i] : ~0ull, on ? nw : ~0ull);
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (vi[h + i] >= 0) {
-                                    const float w = wv[h + i];
-                                    while (prev[i] != seen[i]) {        // lost a race: again on what is there now
-                                        seen[i] = prev[i];
-                                        prev[i] = atomicCAS(&cell[a[i]], seen[i],
-                                                            pack_ws(__uint_as_float((unsigned)seen[i]) + w,
-                                                                    __uint_as_float((unsigned)(seen[i] >> 32)) + w * w));
-                                    }
-                                }
-                        }
-                    }
-                }
-            }
-        };
-        // pass 2 of chunk c: per voxel, frames in order: s *= a_f, k_f = g_f / s
-        auto pass2 = [&](int c) {
-            const int nc = chunk_nc(c);
-            unsigned long long *Ab = A + (size_t)(c & 1) * GC * TV;
-            for (int v = tid; v < TV; v += NT) {
-                float s = sc[v];
-                bool any = false;
-                for (int j = 0; j < nc; ++j) {
-                    const unsigned long long cell = Ab[j * TV + v];
-                    if ((unsigned)cell != 0u) {
-                        const float Wv = __uint_as_float((unsigned)cell), S2 = __uint_as_float((unsigned)(cell >> 32));
-                        const float rW = __builtin_amdgcn_rcpf(Wv);
-                        const float a = 1.0f - P.iw * (S2 * rW);
-                        s *= a;
-                        if (!(s >= RESCALE_BELOW)) {
-                            for (int ch = 0; ch < C; ++ch) D[v * C + ch] *= s;
-                            for (int t = 0; t < j; ++t) reinterpret_cast<float *>(&Ab[t * TV + v])[0] *= s;
-                            s = 1.0f;
-                        }
-                        reinterpret_cast<float *>(&Ab[j * TV + v])[0] = P.iw * rW * __builtin_amdgcn_rcpf(s);
-                        any = true;
-                    }
-                }
-                if (any) sc[v] = s;
-            }
-        };
-        // pass 3 of chunk c: D += k_f * w^2 * feat (rounds of four corners, see fuse_tiles_kernel)
-        auto pass3 = [&](int c) {
-            const int *cbp = cb2 + (c & 1) * (MAX_CHUNK + 1);
-            const int nc = chunk_nc(c);
-            const int ea = cbp[0], eb = cbp[nc];
-            const unsigned long long *Ab = A + (size_t)(c & 1) * GC * TV;
-            unsigned *Du = reinterpret_cast<unsigned *>(D);
-            const int bb0 = t_a + (ea - t_a) / (NT * EB) * (NT * EB);
-            for (int bb = bb0; bb < eb; bb += NT * EB) {
-                uint4 r[EB];
-                uint32_t x[EB];
-                if (bb == t_a) {
-#pragma unroll
-                    for (int j = 0; j < EB; ++j) { r[j] = pre[j]; x[j] = prex[j]; }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < EB; ++j) {
-                        const int e = bb + tid + j * NT;
-                        x[j] = 0;
-                        if (e >= ea && e < eb) { r[j] = P.rec[e]; if (KIND == 1) x[j] = P.aux[e]; }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < EB; ++j) {
-                    const int e = bb + tid + j * NT;
-                    if (e >= ea && e < eb && (KIND == 0 || x[j] < (uint32_t)C)) {
-                        int slot = 0;
-                        for (int q = 1; q < nc; ++q) slot += e >= cbp[q];
-                        const int base = slot * TV;
-                        int vi[8];
-                        float qv[8];
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
-                        for_corners_idx(P, r[j], o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
-                        int vf = 0;
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
-#pragma unroll
-                        for (int h = 0; h < 8; h += 4) {                 // branch-free rounds, as in pass 1
-                            unsigned seen[4], prev[4];
-                            int a[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                a[i] = vi[h + i] >= 0 ? vi[h + i] : vf;
-                                qv[h + i] *= klow(Ab, base + a[i]);
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                a[i] = KIND == 0 ? a[i] : a[i] * C + (int)x[j];
-                                seen[i] = Du[a[i]];
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const bool on = vi[h + i] >= 0;
-                                prev[i] = atomicCAS(&Du[a[i]], on ? seen[i] : 0xffffffffu,
-                                                    on ? __float_as_uint(__uint_as_float(seen[i]) + qv[h + i]) : 0xffffffffu);
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (vi[h + i] >= 0 && prev[i] != seen[i]) atomicAdd(&D[a[i]], qv[h + i]);
-                        }
-                    }
-                }
-            }
-        };
 
-        // ---- prologue: pass 1 and pass 2 of chunk 0
-        pass1(0);
-        zero_cells(1);
-        write_cb(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the preload
-        if (tid == 0) {                                              // advance the ticket pipeline (see fuse_tiles_kernel)
-            misc[2] = act_pend;
+        // ---- pass 1: W, S2 of every (voxel, frame) cell
+        const int dbg = P.vec4 >> 8;     // dev: timing experiments (MF_DBG)
+        auto p1_record = [&](const uint4 &r) {
+            if (dbg & 1) { if (r.y == 0x12345u) A[0] = 1ull; return; }
+            const int f = rec_group(r);
+            unsigned long long *cell = A + (size_t)f * TVP * 2;
+            const unsigned long long bit = 1ull << f;
+            for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                atomicAdd(&cell[2 * v], to_fixed(w, fx_c));
+                atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
+                atomicOr(&mask[v], bit);
+            });
+        };
+        // the tile's first NT * EB records are in registers: straight-line code (a loop header would make the
+        // compiler wait for every outstanding memory operation, the previous tile's stores included)
+#pragma unroll
+        for (int j = 0; j < EB; ++j)
+            if (ts + tid + j * NT < te) p1_record(pre[j]);
+        for (int bb = ts + NT * EB; bb < te; bb += NT * EB) {
+            uint4 r[EB];
+#pragma unroll
+            for (int j = 0; j < EB; ++j) r[j] = P.rec[min(bb + tid + j * NT, te - 1)];
+#pragma unroll
+            for (int j = 0; j < EB; ++j)
+                if (bb + tid + j * NT < te) p1_record(r[j]);
+        }
+        MF_STAMP(6)
+        if (tid == 0) {                                  // advance the look-ups
+            misc[8] = nx_tile; misc[9] = nx_s; misc[10] = nx_e;
+            nx_tile = rng_tile; nx_s = rng_s; nx_e = rng_e;
+            rng_tile = act_pend;
+            range_of(rng_tile, rng_s, rng_e);
             act_pend = resolve(idx_pend);
             idx_pend = atomicAdd(P.ticket, 1);
         }
         barrier_keep_vm();
         MF_STAMP(2)
-        pass2(0);
-        barrier_keep_vm();
-        MF_STAMP(3)
-        for (int c = 0; c < n_chunks; ++c) {
-            pass3(c);
-            if (c + 1 < n_chunks) pass1(c + 1);
-            if (c == 0 && tile_next >= 0) store_offs(offs2 + (buf ^ 1) * (MAX_GROUPS + 1), onext);
-            if (c + 1 == n_chunks) break;
-            barrier_keep_vm();
-            MF_STAMP(4)
-            zero_cells(c + 2);
-            pass2(c + 1);
-            write_cb(c + 2);
-            barrier_keep_vm();
-            MF_STAMP(5)
-        }
-        if (tile_next >= 0) prefetch_entries(offs2 + (buf ^ 1) * (MAX_GROUPS + 1));   // lands during the final pass
-        barrier_keep_vm();
-        MF_STAMP(4)
 
-        // ---- final pass: every row of the tile is written as s * D (untouched voxels: s = 1, D = old value)
-        {
-            const unsigned row_len = (unsigned)C << P.s2;
-            const unsigned n4 = n_el >> 2;
-            float4 *map4w = reinterpret_cast<float4 *>(P.map);
-            for (unsigned q = tid; q < n4; q += NT) {
-                const unsigned i = q << 2;
-                const unsigned v0 = div_magic(i, P.magicC), v3 = div_magic(i + 3, P.magicC);
-                const unsigned v1 = C < 3 ? div_magic(i + 1, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 1, P.magicC));
-                const unsigned v2 = C < 3 ? div_magic(i + 2, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 2, P.magicC));
-                const unsigned r = v0 >> P.s2;
-                const int l1 = r & m1, l0 = r >> P.s1;
-                if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
-                    const size_t g = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len);
-                    const float4 d = *reinterpret_cast<const float4 *>(D + i);
-                    float4 o;
-                    o.x = sc[v0] * d.x; o.y = sc[v1] * d.y; o.z = sc[v2] * d.z; o.w = sc[v3] * d.w;
-                    map4w[g >> 2] = o;
+        // ---- the next tile's first records and current map values start coming in (used after pass 3)
+        const int tile_n = misc[8], ts_n = misc[9], te_n = misc[10];
+        if (tile_n >= 0) {
+            prefetch_entries(ts_n, te_n, pre_n, prex_n);
+            MF_FETCH_OLD(tile_n)
+        }
+
+        MF_STAMP(5)
+        // ---- pass 2: per voxel t_f = g_f * prod_{f' > f} a_f' into the cells, D *= prod_f a_f
+        // PP lanes per voxel, each with FP consecutive frames, of which it visits those in the voxel's mask
+        if (!(dbg & 4)) {
+            const int v = tid / PP, p = tid - v * PP;
+            if (v < TV) {
+                const int f0 = p * FP;
+                const unsigned long long mine = FP >= 64 ? mask[v] : f0 >= 64 ? 0ull : (mask[v] >> f0) & ((1ull << FP) - 1ull);
+                float prod = 1.0f;
+                for (unsigned long long m = mine; m; m &= m - 1ull) {
+                    const unsigned long long *c = A + ((size_t)(f0 + __builtin_ctzll(m)) * TVP + v) * 2;
+                    const float rW = __builtin_amdgcn_rcpf((float)c[0] * fx_inv);
+                    prod *= 1.0f - P.iw * (((float)c[1] * fx_inv) * rW);
                 }
+                float x = prod;                          // -> product over this and all later parts of the voxel
+                for (int d = 1; d < PP; d <<= 1) {
+                    const float y = __shfl_down(x, d, 64);
+                    if (p + d < PP) x *= y;
+                }
+                float run = __shfl_down(x, 1, 64);       // product over the later parts
+                if (p + 1 >= PP) run = 1.0f;
+                const float total = __shfl(x, (tid & 63) - p, 64);
+                for (unsigned long long m = mine; m;) {  // latest frame first
+                    const int j = 63 - __builtin_clzll(m);
+                    m ^= 1ull << j;
+                    unsigned long long *c = A + ((size_t)(f0 + j) * TVP + v) * 2;
+                    const float rW = __builtin_amdgcn_rcpf((float)c[0] * fx_inv);
+                    const float a = 1.0f - P.iw * (((float)c[1] * fx_inv) * rW);
+                    reinterpret_cast<float *>(c)[0] = P.iw * rW * run;
+                    run *= a;
+                }
+                if (total != 1.0f)
+                    for (int ch = p; ch < C; ch += PP) Dc[v * C + ch] *= total;
             }
         }
         barrier_keep_vm();
-        MF_STAMP(6)
-        tile = tile_next;
-        tile_next = misc[2];
-        buf ^= 1;
+        MF_STAMP(3)
+
+        // ---- pass 3: D += t_f * w^2 * feat (branch-free rounds of four corners, as in pass 1)
+        {
+            unsigned *Du = reinterpret_cast<unsigned *>(Dc);
+            auto p3_record = [&](const uint4 &r, uint32_t x) {
+                if (dbg & 2) { if (r.y == 0x12345u) Du[0] = 1u; return; }
+            const unsigned long long *cell = A + (size_t)rec_group(r) * TVP * 2;
+            int vi[8];
+            float qv[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
+            for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+            int vf = 0;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
+#pragma unroll
+            for (int h = 0; h < 8; h += 4) {
+                unsigned seen[4], prev[4];
+                int a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = vi[h + i] >= 0 ? vi[h + i] : vf;
+                    qv[h + i] *= klow(cell, 2 * a[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = KIND == 0 ? a[i] : a[i] * C + (int)x;
+                    seen[i] = Du[a[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool on = vi[h + i] >= 0;
+                    prev[i] = atomicCAS(&Du[a[i]], on ? seen[i] : 0xffffffffu,
+                                        on ? __float_as_uint(__uint_as_float(seen[i]) + qv[h + i]) : 0xffffffffu);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (vi[h + i] >= 0 && prev[i] != seen[i]) atomicAdd(&Dc[a[i]], qv[h + i]);
+            }
+            };
+#pragma unroll
+            for (int j = 0; j < EB; ++j)
+                if (ts + tid + j * NT < te && (KIND == 0 || prex[j] < (uint32_t)C)) p3_record(pre[j], prex[j]);
+            for (int bb = ts + NT * EB; bb < te; bb += NT * EB) {
+                uint4 r[EB];
+                uint32_t x[EB];
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int e = min(bb + tid + j * NT, te - 1);
+                    r[j] = P.rec[e];
+                    x[j] = KIND == 1 ? P.aux[e] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < EB; ++j)
+                    if (bb + tid + j * NT < te && (KIND == 0 || x[j] < (uint32_t)C)) p3_record(r[j], x[j]);
+            }
+        }
+        barrier_keep_vm();
+        MF_STAMP(4)
+        // ---- this tile's rows go out (every row whole: an untouched voxel is rewritten with the value it
+        // had); the next tile's values take their place
+#pragma unroll
+        for (int j = 0; j < OVM; ++j) {
+            size_t g4;
+            const unsigned q = tid + j * NT;
+            if (elem_index(tile, q, g4)) map4[g4] = reinterpret_cast<const v4f *>(Dc)[q];
+        }
+        if (tile_n < 0) break;
+#pragma unroll
+        for (int j = 0; j < OVM; ++j) {
+            size_t g4;
+            const unsigned q = tid + j * NT;
+            if (elem_index(tile_n, q, g4)) reinterpret_cast<v4f *>(Dc)[q] = oldv[j];
+        }
+        {                                                // clear the cells this tile touched, and the masks
+            const int v = tid / PP, p = tid - v * PP;
+            if (v < TV) {
+                const int f0 = p * FP;
+                const unsigned long long all = mask[v];
+                const unsigned long long mine = FP >= 64 ? all : f0 >= 64 ? 0ull : (all >> f0) & ((1ull << FP) - 1ull);
+                for (unsigned long long m = mine; m; m &= m - 1ull) {
+                    unsigned long long *c = A + ((size_t)(f0 + __builtin_ctzll(m)) * TVP + v) * 2;
+                    c[0] = 0ull; c[1] = 0ull;
+                }
+                if (p == 0 && all) mask[v] = 0ull;
+            }
+        }
+        tile = tile_n; ts = ts_n; te = te_n;
+#pragma unroll
+        for (int j = 0; j < EB; ++j) { pre[j] = pre_n[j]; prex[j] = prex_n[j]; }
     }
-    if (STAMPS && tid == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], stamp_acc[i]);
+    if (STAMPS && tid == 0) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 7; ++i) { atomicAdd(&g_stamps[i], stamp_acc[i]); tot += stamp_acc[i]; }
+        atomicMax(&g_stamps[7], tot);                   // the slowest workgroup
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -1364,7 +1318,7 @@ __global__ __launch_bounds__(NT) void fuse_single_kernel(SingleParams P)
     const float fx_inv2 = fx_inv * 5.8207661e-11f;                               // 2^-34
     // for_corners wants the tile kernel's parameter block: only the geometry fields are read
     TileParams T;
-    T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = C; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2;
+    T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = C; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2; T.G = 1;
     const int n_items = P.ticket[SPLIT_ITEMS];
 
     // the next item's descriptor and record range are looked up while the current item is processed
@@ -1575,7 +1529,7 @@ __global__ __launch_bounds__(NT) void fuse_single_dense_kernel(SingleParams P)
     const float ux_inv = __uint_as_float((unsigned)(127 - shift_u) << 23);
     const float ux_inv2 = ux_inv * 5.8207661e-11f;
     TileParams T;
-    T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = C; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2;
+    T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = C; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2; T.G = 1;
     const int n_items = P.ticket[SPLIT_ITEMS];
 
     int it = blockIdx.x, tile = -1, s = 0, e = 0;
@@ -1739,6 +1693,24 @@ static int ilog2_floor(unsigned x) { int l = 0; while ((2u << l) <= x) ++l; retu
 // deltas + scales + flag + four frames of 64-bit W/S2 accumulators per voxel) fits the
 // CU's LDS, capped at 512 voxels (8 x 8 x 8); z gets up to 8 so that HBM runs stay long.
 // Tuning override for experiments: MF_TILE="s0 s1 s2 threads" (log2 extents).
+// fuse_sparse_kernel: G rows of (TV + 1) 16-byte cells, a mask per voxel, the tile image, a few words
+static size_t sparse_lds_bytes(int C, int sv, int G)
+{
+    const size_t TV = (size_t)1 << sv;
+    return (size_t)G * (TV + 1) * 16 + TV * 8 + TV * C * 4 + 16 * 4 + 16;
+}
+
+// Calls of several sequential frames are bucketed on 4 x 4 x 8 tiles when the sparse variant of the tile
+// kernel could take them (whether it does is decided on the device, after counting): its cells for all the
+// frames and three tile images have to fit, with a few KB left for the bucketing kernels of the next batch.
+constexpr int SPARSE_SV = 7;
+static bool sparse_shape(const mf_grid *g, int G)
+{
+    static const bool on = !(getenv("MF_SPARSE") && atoi(getenv("MF_SPARSE")) == 0);
+    return on && G > 2 && G <= SPARSE_MAX_GC && sparse_lds_bytes(g->channels, SPARSE_SV, G) <= 160 * 1024 &&
+           ((size_t)g->channels << SPARSE_SV) / 4 <= 4 * 512;          // the tile image in 4 float4 registers of 512 threads
+}
+
 static int g_gc_override = -1;
 static bool tile_override(int &s0, int &s1, int &s2, int &nt)
 {
@@ -1758,6 +1730,7 @@ static void choose_tile(const mf_grid *g, int n_groups, int &s0, int &s1, int &s
 {
     int nt_unused;
     if (tile_override(s0, s1, s2, nt_unused)) return;
+    if (sparse_shape(g, n_groups)) { s0 = 2; s1 = 2; s2 = 3; return; }
     const size_t budget = 158 * 1024 - 8 * (MAX_GROUPS + 32) - 2 * MAX_GROUPS;
     size_t per_voxel = (size_t)g->channels * 4 + 8 + 1 + 4 * 16;      // deltas, scales, flag, >= 4 frames of W/S2
     unsigned tv = (unsigned)(budget / per_voxel);
@@ -1788,6 +1761,8 @@ static int chunk_frames(int C, int sv, int G)
     const size_t fixed = tile_lds_fixed(C, sv);
     size_t avail = fixed + per_slot <= 160 * 1024 ? 160 * 1024 - fixed : per_slot;
     if (avail > 64 * 1024) avail = 64 * 1024;
+    // small tiles: four workgroups per CU (their memory and compute phases overlap) matter more than long chunks
+    if (sv <= 7 && fixed + 4 * per_slot <= 40 * 1024) avail = 40 * 1024 - fixed;
     int gc = (int)(avail / per_slot);
     if (g_gc_override > 0) gc = g_gc_override;
     if (gc > MAX_CHUNK) gc = MAX_CHUNK;
@@ -1799,28 +1774,6 @@ static int chunk_frames(int C, int sv, int G)
 static size_t tile_lds_bytes(int C, int sv, int gc)
 {
     return tile_lds_fixed(C, sv) + (size_t)gc * ((size_t)1 << sv) * 16;
-}
-
-// fuse_sparse_kernel: deltas, s, two offset arrays, two chunk layouts, misc, non-empty list; per chunk frame
-// two buffers of 8-byte cells
-static size_t sparse_lds_fixed(int C, int sv)
-{
-    const size_t TV = (size_t)1 << sv;
-    return TV * C * 4 + TV * 4 + 2 * (MAX_GROUPS + 1) * 4 + 2 * (MAX_CHUNK + 1) * 4 + 8 * 4 + MAX_GROUPS * 2 + 16;
-}
-
-static int sparse_chunk_frames(int C, int sv, int G)
-{
-    const size_t per_slot = ((size_t)1 << sv) * 16;
-    const size_t fixed = sparse_lds_fixed(C, sv);
-    size_t avail = fixed + per_slot <= 160 * 1024 ? 160 * 1024 - fixed : per_slot;
-    if (avail > 64 * 1024) avail = 64 * 1024;
-    int gc = (int)(avail / per_slot);
-    if (g_gc_override > 0) gc = g_gc_override;
-    if (gc > MAX_CHUNK) gc = MAX_CHUNK;
-    if (gc > G) gc = G;
-    if (gc < 1) gc = 1;
-    return gc;
 }
 
 struct Layout {
@@ -2019,14 +1972,15 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     int blocks = dev.cus * per_cu;
     { static const int cap = getenv("MF_BLOCKS") ? atoi(getenv("MF_BLOCKS")) : 0; if (cap > 0 && blocks > cap) blocks = cap; }   // dev: fewer workgroups
     if (blocks > P.n_tiles) blocks = P.n_tiles;
-    // sparse variant of the tile kernel (class ids / ones, several sequential frames, float4 rows): offered to
-    // the call when it would run with the same grid; tile_list_kernel decides on the device which of the two runs
-    static const bool sparse_on = !(getenv("MF_SPARSE") && atoi(getenv("MF_SPARSE")) == 0);
-    int sgc = sparse_chunk_frames(P.C, sv, P.G);
-    if (phase != 3 && sgc > 2) sgc -= 1;
-    const size_t slds_sparse = sparse_lds_fixed(P.C, sv) + (size_t)sgc * ((size_t)16 << sv);
-    const bool sparse = sparse_on && P.feat_kind != MF_FEAT_DENSE_F32 && P.vec4 && P.G > 1 && nt >= 64 &&
-                        slds_sparse <= (size_t)dev.lds_per_cu && (int)((size_t)dev.lds_per_cu / slds_sparse) >= per_cu;
+    // sparse variant of the tile kernel (class ids / ones, several sequential frames, float4 rows, 4 x 4 x 8
+    // tiles): launched next to the tile kernel, tile_list_kernel decides on the device which of the two runs
+    static const int sparse_nt = getenv("MF_SPARSE_NT") ? atoi(getenv("MF_SPARSE_NT")) : 512;
+    const size_t slds_sparse = sparse_lds_bytes(P.C, sv, P.G);
+    const bool sparse = sparse_shape(grid, P.G) && sv == SPARSE_SV && P.s2 == 3 && P.feat_kind != MF_FEAT_DENSE_F32 &&
+                        P.vec4 && slds_sparse <= (size_t)dev.lds_per_cu;
+    int blocks_sparse = dev.cus * (int)((size_t)dev.lds_per_cu / (slds_sparse ? slds_sparse : 1));
+    { static const int cap = getenv("MF_BLOCKS") ? atoi(getenv("MF_BLOCKS")) : 0; if (cap > 0 && blocks_sparse > cap) blocks_sparse = cap; }
+    if (blocks_sparse > P.n_tiles) blocks_sparse = P.n_tiles;
 
     if (phase & 1) {
     prof_mark(0, st);
@@ -2050,7 +2004,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
                        P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
                        (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks,
-                       sparse ? SPARSE_MAX_MEAN : 0);
+                       sparse ? SPARSE_MAX_MEAN : 0, 4 * blocks_sparse);
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
@@ -2096,11 +2050,12 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);      // returns at once when the call went to the single-pass kernel
     MF_LAUNCH_CHECK("fuse_tiles_kernel");
     if (sparse) {
+        const int snt = sparse_nt >= 1024 ? 1024 : 512;
         void (*sk)(TileParams);
-        if (nt <= 64) sk = kind == 0 ? fuse_sparse_kernel<0, 64> : fuse_sparse_kernel<1, 64>;
-        else if (nt <= 256) sk = kind == 0 ? fuse_sparse_kernel<0, 256> : fuse_sparse_kernel<1, 256>;
-        else sk = kind == 0 ? fuse_sparse_kernel<0, 1024> : fuse_sparse_kernel<1, 1024>;
-        if (stamps && nt > 256) sk = kind == 0 ? fuse_sparse_kernel<0, 1024, true> : fuse_sparse_kernel<1, 1024, true>;
+        if (snt >= 1024) sk = stamps ? (kind == 0 ? fuse_sparse_kernel<0, 1024, true> : fuse_sparse_kernel<1, 1024, true>)
+                                     : (kind == 0 ? fuse_sparse_kernel<0, 1024> : fuse_sparse_kernel<1, 1024>);
+        else sk = stamps ? (kind == 0 ? fuse_sparse_kernel<0, 512, true> : fuse_sparse_kernel<1, 512, true>)
+                         : (kind == 0 ? fuse_sparse_kernel<0, 512> : fuse_sparse_kernel<1, 512>);
         {
             static std::mutex mu3;
             static std::unordered_map<const void *, size_t> granted3;
@@ -2112,8 +2067,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
             }
         }
         TileParams S = T;
-        S.gc = sgc;
-        hipLaunchKernelGGL(sk, dim3(blocks), dim3(nt), slds_sparse, st, S);   // returns at once unless tile_list_kernel chose it
+        { static const int dbg = getenv("MF_DBG") ? atoi(getenv("MF_DBG")) : 0; S.vec4 |= dbg << 8; }
+        hipLaunchKernelGGL(sk, dim3(blocks_sparse), dim3(snt), slds_sparse, st, S);   // returns at once unless tile_list_kernel chose it
         MF_LAUNCH_CHECK("fuse_sparse_kernel");
     }
     if (single) {
@@ -2157,6 +2112,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         fprintf(stderr, "[MF_STAMPS] blocks=%d nt=%d lds=%zu gc=%d | ticket+offs %.1f%% setup %.1f%% chunk-zero %.1f%% P1 %.1f%% P2 %.1f%% P3 %.1f%% final %.1f%% | total %.3g ticks/block\n",
                 blocks, nt, lds, P.gc, 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot,
                 100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot, tot / blocks);
+        if (z[7]) fprintf(stderr, "[MF_STAMPS] sparse kernel: %d workgroups, mean %.3g ticks, slowest %.3g | look-ups %.1f%% zero %.1f%% pass1 %.1f%% wait %.1f%% out+in issue %.1f%% pass2 %.1f%% pass3 %.1f%%\n", blocks_sparse,
+                          tot / blocks_sparse, (double)z[7], 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[6] / tot, 100 * z[2] / tot, 100 * z[5] / tot, 100 * z[3] / tot, 100 * z[4] / tot);
     }
     return MF_OK;
 }
