@@ -353,7 +353,8 @@ __device__ __forceinline__ int tile_class(int n)
 // every non-empty tile, one with more than split_min records cut into `nparts` record ranges.
 constexpr int SPLIT_ITEMS = ABORT_SLOT + 1, SPLIT_TILES = ABORT_SLOT + 2, SPLIT_NONEMPTY = ABORT_SLOT + 3;
 constexpr int FEAT_ABSMAX = ABORT_SLOT + 4;     // bits of max |feature| of the call (dense single-pass path)
-constexpr int MODE_SLOT = ABORT_SLOT + 5;       // 1: the call's frames are sparse, fuse_sparse_kernel takes it (else fuse_tiles_kernel)
+constexpr int MODE_SLOT = ABORT_SLOT + 5;       // which tile kernel takes the call: 0 fuse_tiles_kernel, 2 fuse_dense_kernel
+constexpr int HINT_SLOT = ABORT_SLOT + 6;       // [2] records listed, non-empty buckets x tile voxels / 2: read back by the host (tile_hint)
 constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
 constexpr int SPLIT_PARTS_MAX = 64;
@@ -362,16 +363,20 @@ constexpr long long SINGLE_MAX_POINTS = 1 << 21;   // calls with more points (a 
 __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
                                                         int n_tiles, int G, int *ticket, int *active,
                                                         int split_min, int split_part, int split_slots, int *items,
-                                                        int min_mean, int first_ticket, int sparse_max_mean,
-                                                        int first_ticket_sparse)
+                                                        int min_mean, int first_ticket, int dense_tv,
+                                                        int first_ticket_dense)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
-        // few records per non-empty (tile, frame) bucket on average: the sparse variant of the tile kernel
-        const bool sparse = sparse_max_mean > 0 &&
-                            (long long)cursor[n_tiles * G] <= (long long)ticket[SPLIT_NONEMPTY] * sparse_max_mean;
-        ticket[MODE_SLOT] = sparse;
-        ticket[0] = sparse ? first_ticket_sparse : first_ticket;   // the tile kernels deal their first items statically (see there)
+        // Density of the call: records per non-empty (tile, frame) bucket and tile voxel.  Half a record per
+        // voxel and frame or more is a real scene (a batch of unrelated frames has 0.03): the all-integer
+        // tile kernel takes it when the call was bucketed on its tiles (dense_tv = their voxel count, else 0).
+        const long long total = cursor[n_tiles * G], half = (long long)ticket[SPLIT_NONEMPTY] * (dense_tv > 0 ? dense_tv : 512) / 2;
+        const bool dense = dense_tv > 0 && total >= half;
+        ticket[MODE_SLOT] = dense ? 2 : 0;
+        ticket[HINT_SLOT] = (int)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
+        ticket[HINT_SLOT + 1] = (int)(half > 0x7fffffffLL ? 0x7fffffffLL : half);
+        ticket[0] = dense ? first_ticket_dense : first_ticket;   // the tile kernels deal their first items statically (see there)
     }
     int n = 0;
     if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     // wait (the old-map preload): nothing else is outstanding there, so reading the results of the
     // loads issued one tile earlier costs no wait of its own (vmcnt retires in order: waiting for an
     // old load at any other point would also wait for every younger load and store of the wave).
-    if (P.ticket[MODE_SLOT] == 1) return;                                        // fuse_sparse_kernel takes the call (uniform)
+    if (P.ticket[MODE_SLOT] != 0) return;                                        // fuse_dense_kernel takes the call (uniform)
     if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;      // nothing listed (uniform)
     // The first four work items of a workgroup are dealt statically, list positions b, b + n, b + 2n,
     // b + 3n for workgroup b of n: the list is heaviest first, so every workgroup starts on one of the
@@ -914,39 +919,33 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 
 
 // ----------------------------------------------------------------------------
-// tile kernel for sparse frames
+// tile kernel for dense frames (real scenes)
 // ----------------------------------------------------------------------------
-// A batch of unrelated frames (SURVEY 8(d) distribution A) leaves ~16 records per 8 x 8 x 8 tile and
-// frame.  fuse_tiles_kernel then spends its time in chunk phases that are a barrier plus two or three
-// LDS round trips each with most lanes idle, and one workgroup per CU alternates between moving
-// the tile (a CU on its own streams ~25 GB/s) and computing on it.  This variant is built the other
-// way round, on 4 x 4 x 8 tiles:
-//   * ALL frames of the call are one chunk: 64 frames x 128 voxels of 16-byte cells (W, S2 as 64-bit
-//     fixed point: integer LDS atomics need no return value, so pass 1 has no latency chain; a pair
-//     of floats updated by 64-bit compare-and-swap was 2.5x slower, the records of a frame sit in
-//     the same wave and collide) are 129 KB, and a tile costs four barriers in all; a 64-bit mask
-//     per voxel remembers the frames that touched it, so that pass 2 and the clearing of the cells
-//     visit only those (a quarter of the cells);
+// A real trajectory puts hundreds to thousands of records into a tile per frame, 30-140 of them on
+// the same voxel with the same class.  fuse_tiles_kernel adds its fp32 deltas by compare-and-swap:
+// lanes that meet on a word lose the swap and fall back to ds_add_f32 (29x slower than an integer
+// atomic), which is where such batches spend their time.  This variant keeps EVERYTHING it
+// accumulates as integers, on 4 x 4 x 8 tiles (four times the workgroups for a scene that sits on
+// few tiles):
+//   * W, S2 per (voxel, frame) cell as 64-bit fixed point, for a chunk of `gc` frames at a time;
 //   * the frame of a record travels in the record (spare bits, see scatter_kernel): no per-tile
 //     offset table, no search;
-//   * the unrolled blend is written with SUFFIX products: m_n = (prod_f a_f) m_0 + sum_f t_f U_f,
-//     t_f = g_f * prod_{f' > f} a_f'  -- no division by a running scale, nothing to rescale;
-//   * the next tile's map values are fetched into registers while this tile is computed (512 threads:
-//     256 VGPRs each) and swapped into D as this tile's rows are stored, so the CU streams all the
-//     time.  (LDS-DMA is not used here: after a global_load_lds the compiler makes every later LDS
-//     read of the same array wait for vmcnt(0), which would serialise exactly what is to overlap.)
-// Calls whose frames are dense (long tiles; pass 3 adds floats by compare-and-swap) stay with fuse_tiles_kernel;
-// tile_list_kernel decides per call (ticket[MODE_SLOT]).
-constexpr int SPARSE_MAX_MEAN = 128;      // mean records per non-empty (tile, frame) bucket up to which a call is "sparse"
-constexpr int SPARSE_MAX_GC = 64;         // frames of a call (= cells per voxel)
-
-__device__ __forceinline__ unsigned long long pack_ws(float w, float s2)
-{
-    return (unsigned long long)__float_as_uint(w) | ((unsigned long long)__float_as_uint(s2) << 32);
-}
+//   * the unrolled blend is written with SUFFIX products, m_n = (prod_f a_f) m_0 + sum_f t_f U_f with
+//     t_f = g_f * prod_{f' > f} a_f' (per chunk; a later chunk multiplies what is there by its own
+//     product): every added term t_f w^2 lies in [0, 1], so the deltas D are 64-bit fixed point too
+//     (40 fraction bits; a positive term below one unit adds one unit, so that "non-zero" survives)
+//     and pass 3 is one dependent LDS read and integer atomics that return nothing;
+//   * the old map values never enter LDS: they are combined with prod a and D when the rows are stored
+//     (two workgroups per CU: one computes while the other moves its rows).
+// Sums are exact and order independent: the result is run-to-run identical.
+// tile_list_kernel decides per call which tile kernel runs (ticket[MODE_SLOT]); the host picks the
+// tile shape from what the previous call on the same workspace counted (see tile_hint).
+constexpr int DENSE_SV = 7;               // 4 x 4 x 8 tiles
+constexpr int DENSE_FX = 40;              // fraction bits of the deltas
+constexpr int DENSE_MAX_CHUNKS = 32;
 
 template <int KIND, int MAXT, bool STAMPS = false>
-__global__ __launch_bounds__(MAXT) void fuse_sparse_kernel(TileParams P)
+__global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      // four waves per SIMD: two workgroups of 512 per CU
 {
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -954,18 +953,22 @@ __global__ __launch_bounds__(MAXT) void fuse_sparse_kernel(TileParams P)
     const int tid = threadIdx.x, NT = blockDim.x;
     const int C = P.C;
     const int sv = P.s0 + P.s1 + P.s2;
-    const int TV = 1 << sv, TVP = TV + 1;          // cell rows are padded by one: pass 2 reads them strided by frames
-    const int G = P.G;
+    const int TV = 1 << sv, TVP = TV + 1;
+    const int G = P.G, GC = P.gc;
+    const int n_chunks = (G + GC - 1) / GC;
     const int m1 = (1 << P.s1) - 1;
     const unsigned n_el = (unsigned)TV * (unsigned)C;
-    unsigned long long *A = reinterpret_cast<unsigned long long *>(smem);      // [G][TV + 1][2] W, S2; low word of W = t_f after pass 2
-    unsigned long long *mask = A + (size_t)G * TVP * 2;                        // [TV] frames that touched the voxel
-    float *Dc = reinterpret_cast<float *>(mask + TV);                          // [TV][C] the tile: old values, then the result
+    unsigned long long *A = reinterpret_cast<unsigned long long *>(smem);      // [GC][TV + 1][2] W, S2; low word of W = t_f after pass 2
+    unsigned long long *Di = A + (size_t)GC * TVP * 2;                         // [TV][C] deltas, units of 2^-DENSE_FX
+    float *atot = reinterpret_cast<float *>(Di + n_el);                        // [TV] prod a over the frames so far
+    int *misc = reinterpret_cast<int *>(atot + TV);                            // [0] tile, [4..7] class sizes, [8] next tile
+    int *offs = misc + 16;                                                     // [n_chunks + 1] record offsets of this tile's chunks
+    int *offs_n = offs + DENSE_MAX_CHUNKS + 2;                                 // the next tile's
     const int fx_c = 182 - P.fx_shift;
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
-    int *misc = reinterpret_cast<int *>(Dc + (size_t)n_el);                    // [0..2] tile, first record, end; [4..7] class sizes; [8..10] next tile
+    const float di_inv = __uint_as_float((unsigned)(127 - DENSE_FX) << 23);    // 2^-DENSE_FX
 
-    if (P.ticket[MODE_SLOT] != 1) return;                                      // fuse_tiles_kernel takes the call (uniform)
+    if (P.ticket[MODE_SLOT] != 2) return;                                      // another tile kernel takes the call (uniform)
     if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;
 
     auto resolve = [&](int idx) {          // work list position -> tile id, -1 past the end
@@ -978,36 +981,43 @@ __global__ __launch_bounds__(MAXT) void fuse_sparse_kernel(TileParams P)
         }
         return tile_id;
     };
-    // The look-ups a tile needs (ticket -> list entry -> record range: three dependent global round
-    // trips) are made by thread 0 several tiles ahead, each advanced once per tile right after the
-    // workgroup's vmcnt(0) point.  The first four list positions of a workgroup are dealt statically
-    // (b, b + n, b + 2n, b + 3n: the list is heaviest first), tickets start at 4n.
-    int idx_pend = -1, act_pend = -1, rng_tile = -1, rng_s = 0, rng_e = 0, nx_tile = -1, nx_s = 0, nx_e = 0;
-    auto range_of = [&](int t, int &s, int &e) {
-        s = 0; e = 0;
-        if (t >= 0) { s = t * G > 0 ? P.cursor[t * G - 1] : 0; e = P.cursor[(t + 1) * G - 1]; }
+    // Look-ups of the tiles ahead (ticket -> list entry -> chunk offsets: three dependent global round
+    // trips), made by wave 0, each advanced once per tile; lane l holds chunk offset l.  The first four
+    // list positions of a workgroup are dealt statically (b, b + n, b + 2n, b + 3n: the list is heaviest
+    // first), tickets start at 4n.
+    auto chunk_off = [&](int t) {          // lane tid: first record of chunk tid of tile t (or the tile's end)
+        int o = 0;
+        if (t >= 0 && tid <= n_chunks) {
+            const int k = t * G + min(tid * GC, G);
+            o = k > 0 ? P.cursor[k - 1] : 0;
+        }
+        return o;
     };
-    if (tid == 0) {
+    int idx_pend = -1, act_pend = -1, rng_tile = -1, rng_off = 0, nx_tile = -1, nx_off = 0;
+    if (tid == 0)
 #pragma unroll
         for (int c = 0; c < TILE_CLASSES; ++c) misc[4 + c] = P.ticket[1 + c];
+    __syncthreads();
+    if (tid < 64) {
         const int nb = gridDim.x, b = blockIdx.x;
         const int t0 = resolve(b);
-        int s0, e0;
-        range_of(t0, s0, e0);
-        misc[0] = t0; misc[1] = s0; misc[2] = e0;
+        const int o0 = chunk_off(t0);
+        if (tid == 0) misc[0] = t0;
+        if (tid <= n_chunks) offs[tid] = o0;
         nx_tile = resolve(b + nb);
-        range_of(nx_tile, nx_s, nx_e);
+        nx_off = chunk_off(nx_tile);
         rng_tile = resolve(b + 2 * nb);
-        range_of(rng_tile, rng_s, rng_e);
+        rng_off = chunk_off(rng_tile);
         act_pend = resolve(b + 3 * nb);
-        idx_pend = atomicAdd(P.ticket, 1);
+        idx_pend = tid == 0 ? atomicAdd(P.ticket, 1) : 0;
+        idx_pend = __shfl(idx_pend, 0, 64);
     }
     __syncthreads();
-    int tile = misc[0], ts = misc[1], te = misc[2];
+    int tile = misc[0];
     if (tile < 0) return;
 
-    uint4 pre[EB], pre_n[EB];
-    uint32_t prex[EB], prex_n[EB];
+    uint4 pre[EB];
+    uint32_t prex[EB];
     auto prefetch_entries = [&](int ta, int tb, uint4 (&q)[EB], uint32_t (&qx)[EB]) {
 #pragma unroll
         for (int j = 0; j < EB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
@@ -1020,10 +1030,8 @@ __global__ __launch_bounds__(MAXT) void fuse_sparse_kernel(TileParams P)
         const int tz = t % P.nt2, ty = (t / P.nt2) % P.nt1, tx = t / (P.nt2 * P.nt1);
         o0 = tx << P.s0; o1 = ty << P.s1; o2 = tz << P.s2;
     };
-    // Thread `tid` owns the float4s tid, tid + NT, ... of the tile image: it fetches the tile's current
-    // values into registers a tile ahead, and at the end of a tile stores the result from D and puts the
-    // next tile's values in its place (its own elements only: no barrier in between).
-    constexpr int OVM = 4;                                  // float4s per thread (the host checks TV * C / 4 <= OVM * 512)
+    // Thread `tid` owns the float4s tid, tid + NT, ... of the tile image (OVM of them at most; the host checks).
+    constexpr int OVM = 4;
     const unsigned n4 = n_el >> 2, row_len = (unsigned)C << P.s2;
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f *map4 = reinterpret_cast<v4f *>(P.map);
@@ -1036,207 +1044,198 @@ __global__ __launch_bounds__(MAXT) void fuse_sparse_kernel(TileParams P)
         g4 = ((((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len)) >> 2;
         return q < n4 && o0 + l0 < P.size0 && o1 + l1 < P.size1;
     };
-    v4f oldv[OVM];
-    // all loads unconditional (an element outside the map reads element 0 and is never used): loads under
-    // separate branches would each wait for the one before
-#define MF_FETCH_OLD(t)                                                                    \
-    _Pragma("unroll") for (int j = 0; j < OVM; ++j) {                                      \
-        size_t g4;                                                                         \
-        const bool in = elem_index(t, tid + j * NT, g4);                                   \
-        oldv[j] = map4[in ? g4 : 0];                                                       \
-    }
 
-    prefetch_entries(ts, te, pre, prex);
-    MF_FETCH_OLD(tile)
-#pragma unroll
-    for (int j = 0; j < OVM; ++j) {
-        size_t g4;
-        if (elem_index(tile, tid + j * NT, g4)) reinterpret_cast<v4f *>(Dc)[tid + j * NT] = oldv[j];
-    }
-    for (int i = tid; i < G * TVP * 2 + TV; i += NT) A[i] = 0ull;            // cells and masks (later: only what a tile touched)
-    // threads of a voxel in pass 2: PP consecutive lanes, each with FP consecutive frames
+    prefetch_entries(offs[0], offs[n_chunks], pre, prex);
+    for (int i = tid; i < GC * TVP * 2 + (int)n_el; i += NT) A[i] = 0ull;        // cells and deltas
+    // threads of a voxel in pass 2: PP consecutive lanes, each with FP consecutive frames of the chunk
     const int PP = NT >> sv > 0 ? NT >> sv : 1;
-    const int FP = (G + PP - 1) / PP;
 
     while (true) {
         int o0, o1, o2;
         tile_origin(tile, o0, o1, o2);
+        const int t_s = offs[0];
+        int tile_n = -1;
         MF_STAMP(0)
-        barrier_keep_vm();                                // cells and masks are clear, D holds the tile's values
-        MF_STAMP(1)
+        for (int c = 0; c < n_chunks; ++c) {
+            const int f_base = c * GC, nc = min(GC, G - f_base);
+            const int ea = offs[c], eb = offs[c + 1];
+            const int FP = (nc + PP - 1) / PP;
+            barrier_keep_vm();                            // cells and masks are clear
+            MF_STAMP(1)
 
-        // ---- pass 1: W, S2 of every (voxel, frame) cell
-        const int dbg = P.vec4 >> 8;     // dev: timing experiments (MF_DBG)
-        auto p1_record = [&](const uint4 &r) {
-            if (dbg & 1) { if (r.y == 0x12345u) A[0] = 1ull; return; }
-            const int f = rec_group(r);
-            unsigned long long *cell = A + (size_t)f * TVP * 2;
-            const unsigned long long bit = 1ull << f;
-            for_corners(P, r, o0, o1, o2, [&](int v, float w) {
-                atomicAdd(&cell[2 * v], to_fixed(w, fx_c));
-                atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
-                atomicOr(&mask[v], bit);
-            });
-        };
-        // the tile's first NT * EB records are in registers: straight-line code (a loop header would make the
-        // compiler wait for every outstanding memory operation, the previous tile's stores included)
-#pragma unroll
-        for (int j = 0; j < EB; ++j)
-            if (ts + tid + j * NT < te) p1_record(pre[j]);
-        for (int bb = ts + NT * EB; bb < te; bb += NT * EB) {
-            uint4 r[EB];
-#pragma unroll
-            for (int j = 0; j < EB; ++j) r[j] = P.rec[min(bb + tid + j * NT, te - 1)];
-#pragma unroll
-            for (int j = 0; j < EB; ++j)
-                if (bb + tid + j * NT < te) p1_record(r[j]);
-        }
-        MF_STAMP(6)
-        if (tid == 0) {                                  // advance the look-ups
-            misc[8] = nx_tile; misc[9] = nx_s; misc[10] = nx_e;
-            nx_tile = rng_tile; nx_s = rng_s; nx_e = rng_e;
-            rng_tile = act_pend;
-            range_of(rng_tile, rng_s, rng_e);
-            act_pend = resolve(idx_pend);
-            idx_pend = atomicAdd(P.ticket, 1);
-        }
-        barrier_keep_vm();
-        MF_STAMP(2)
-
-        // ---- the next tile's first records and current map values start coming in (used after pass 3)
-        const int tile_n = misc[8], ts_n = misc[9], te_n = misc[10];
-        if (tile_n >= 0) {
-            prefetch_entries(ts_n, te_n, pre_n, prex_n);
-            MF_FETCH_OLD(tile_n)
-        }
-
-        MF_STAMP(5)
-        // ---- pass 2: per voxel t_f = g_f * prod_{f' > f} a_f' into the cells, D *= prod_f a_f
-        // PP lanes per voxel, each with FP consecutive frames, of which it visits those in the voxel's mask
-        if (!(dbg & 4)) {
-            const int v = tid / PP, p = tid - v * PP;
-            if (v < TV) {
-                const int f0 = p * FP;
-                const unsigned long long mine = FP >= 64 ? mask[v] : f0 >= 64 ? 0ull : (mask[v] >> f0) & ((1ull << FP) - 1ull);
-                float prod = 1.0f;
-                for (unsigned long long m = mine; m; m &= m - 1ull) {
-                    const unsigned long long *c = A + ((size_t)(f0 + __builtin_ctzll(m)) * TVP + v) * 2;
-                    const float rW = __builtin_amdgcn_rcpf((float)c[0] * fx_inv);
-                    prod *= 1.0f - P.iw * (((float)c[1] * fx_inv) * rW);
-                }
-                float x = prod;                          // -> product over this and all later parts of the voxel
-                for (int d = 1; d < PP; d <<= 1) {
-                    const float y = __shfl_down(x, d, 64);
-                    if (p + d < PP) x *= y;
-                }
-                float run = __shfl_down(x, 1, 64);       // product over the later parts
-                if (p + 1 >= PP) run = 1.0f;
-                const float total = __shfl(x, (tid & 63) - p, 64);
-                for (unsigned long long m = mine; m;) {  // latest frame first
-                    const int j = 63 - __builtin_clzll(m);
-                    m ^= 1ull << j;
-                    unsigned long long *c = A + ((size_t)(f0 + j) * TVP + v) * 2;
-                    const float rW = __builtin_amdgcn_rcpf((float)c[0] * fx_inv);
-                    const float a = 1.0f - P.iw * (((float)c[1] * fx_inv) * rW);
-                    reinterpret_cast<float *>(c)[0] = P.iw * rW * run;
-                    run *= a;
-                }
-                if (total != 1.0f)
-                    for (int ch = p; ch < C; ch += PP) Dc[v * C + ch] *= total;
-            }
-        }
-        barrier_keep_vm();
-        MF_STAMP(3)
-
-        // ---- pass 3: D += t_f * w^2 * feat (branch-free rounds of four corners, as in pass 1)
-        {
-            unsigned *Du = reinterpret_cast<unsigned *>(Dc);
-            auto p3_record = [&](const uint4 &r, uint32_t x) {
-                if (dbg & 2) { if (r.y == 0x12345u) Du[0] = 1u; return; }
-            const unsigned long long *cell = A + (size_t)rec_group(r) * TVP * 2;
-            int vi[8];
-            float qv[8];
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
-            for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
-            int vf = 0;
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
-#pragma unroll
-            for (int h = 0; h < 8; h += 4) {
-                unsigned seen[4], prev[4];
-                int a[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i] = vi[h + i] >= 0 ? vi[h + i] : vf;
-                    qv[h + i] *= klow(cell, 2 * a[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i] = KIND == 0 ? a[i] : a[i] * C + (int)x;
-                    seen[i] = Du[a[i]];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool on = vi[h + i] >= 0;
-                    prev[i] = atomicCAS(&Du[a[i]], on ? seen[i] : 0xffffffffu,
-                                        on ? __float_as_uint(__uint_as_float(seen[i]) + qv[h + i]) : 0xffffffffu);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (vi[h + i] >= 0 && prev[i] != seen[i]) atomicAdd(&Dc[a[i]], qv[h + i]);
-            }
+            // ---- pass 1: W, S2 of every (voxel, frame) cell of the chunk
+            auto p1_record = [&](const uint4 &r) {
+                const int f = rec_group(r) - f_base;
+                unsigned long long *cell = A + (size_t)f * TVP * 2;
+                for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                    atomicAdd(&cell[2 * v], to_fixed(w, fx_c));
+                    atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
+                });
             };
+            // the tile's first NT * EB records are in registers (straight-line code: a loop header would make
+            // the compiler wait for every outstanding memory operation, the previous tile's stores included)
 #pragma unroll
-            for (int j = 0; j < EB; ++j)
-                if (ts + tid + j * NT < te && (KIND == 0 || prex[j] < (uint32_t)C)) p3_record(pre[j], prex[j]);
-            for (int bb = ts + NT * EB; bb < te; bb += NT * EB) {
+            for (int j = 0; j < EB; ++j) {
+                const int e = t_s + tid + j * NT;
+                if (e >= ea && e < eb) p1_record(pre[j]);
+            }
+            for (int bb = max(ea, t_s + NT * EB); bb < eb; bb += NT * EB) {
                 uint4 r[EB];
-                uint32_t x[EB];
 #pragma unroll
-                for (int j = 0; j < EB; ++j) {
-                    const int e = min(bb + tid + j * NT, te - 1);
-                    r[j] = P.rec[e];
-                    x[j] = KIND == 1 ? P.aux[e] : 0u;
-                }
+                for (int j = 0; j < EB; ++j) r[j] = P.rec[min(bb + tid + j * NT, eb - 1)];
 #pragma unroll
                 for (int j = 0; j < EB; ++j)
-                    if (bb + tid + j * NT < te && (KIND == 0 || x[j] < (uint32_t)C)) p3_record(r[j], x[j]);
+                    if (bb + tid + j * NT < eb) p1_record(r[j]);
             }
-        }
-        barrier_keep_vm();
-        MF_STAMP(4)
-        // ---- this tile's rows go out (every row whole: an untouched voxel is rewritten with the value it
-        // had); the next tile's values take their place
+            MF_STAMP(6)
+            if (c == 0 && tid < 64) {                    // advance the look-ups
+                if (tid == 0) misc[8] = nx_tile;
+                if (tid <= n_chunks) offs_n[tid] = nx_off;
+                nx_tile = rng_tile; nx_off = rng_off;
+                rng_tile = act_pend;
+                rng_off = chunk_off(rng_tile);
+                act_pend = resolve(idx_pend);
+                idx_pend = tid == 0 ? atomicAdd(P.ticket, 1) : 0;
+                idx_pend = __shfl(idx_pend, 0, 64);
+            }
+            barrier_keep_vm();
+            MF_STAMP(2)
+
+            if (c == 0) tile_n = misc[8];
+            MF_STAMP(5)
+
+            // ---- pass 2: per voxel t_f = g_f * prod_{f' > f} a_f' into the cells; prod a over the chunk
+            // multiplies what the earlier chunks left (deltas and the factor of the old value)
+            {
+                const int v = tid / PP, p = tid - v * PP;
+                if (v < TV) {
+                    const int f0 = p * FP, f1 = min(nc, f0 + FP);
+                    float prod = 1.0f;
+                    bool any = false;
+                    for (int f = f0; f < f1; ++f) {
+                        const unsigned long long *cl = A + ((size_t)f * TVP + v) * 2;
+                        if (cl[0] != 0ull) {
+                            const float rW = __builtin_amdgcn_rcpf((float)cl[0] * fx_inv);
+                            prod *= 1.0f - P.iw * (((float)cl[1] * fx_inv) * rW);
+                            any = true;
+                        }
+                    }
+                    float x = prod;                      // -> product over this and all later parts of the voxel
+                    for (int d = 1; d < PP; d <<= 1) {
+                        const float y = __shfl_down(x, d, 64);
+                        if (p + d < PP) x *= y;
+                    }
+                    float run = __shfl_down(x, 1, 64);   // product over the later parts
+                    if (p + 1 >= PP) run = 1.0f;
+                    const float total = __shfl(x, (tid & 63) - p, 64);
+                    const bool touched = __any(any) && (__ballot(any) >> ((tid & 63) - p) & ((1ull << PP) - 1ull)) != 0ull;
+                    for (int f = f1 - 1; f >= f0; --f) {       // latest frame first
+                        unsigned long long *cl = A + ((size_t)f * TVP + v) * 2;
+                        if (cl[0] != 0ull) {
+                            const float rW = __builtin_amdgcn_rcpf((float)cl[0] * fx_inv);
+                            const float a = 1.0f - P.iw * (((float)cl[1] * fx_inv) * rW);
+                            reinterpret_cast<float *>(cl)[0] = P.iw * rW * run;
+                            run *= a;
+                        }
+                    }
+                    if (c == 0) {
+                        if (p == 0) atot[v] = total;
+                    } else if (touched) {
+                        if (p == 0) atot[v] *= total;
+                        for (int ch = p; ch < C; ch += PP) {
+                            const unsigned long long d = Di[v * C + ch];
+                            if (d != 0ull) {
+                                unsigned long long nd = (unsigned long long)((double)d * (double)total);
+                                if (nd == 0ull && total > 0.0f) nd = 1ull;      // "non-zero" survives
+                                Di[v * C + ch] = nd;
+                            }
+                        }
+                    }
+                }
+            }
+            barrier_keep_vm();
+            MF_STAMP(3)
+
+            // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1): the t_f of a record's corners are
+            // read together (a corner outside the tile reads that of one inside), then integer atomics
+            {
+                auto p3_record = [&](const uint4 &r, uint32_t x) {
+                    const unsigned long long *cell = A + (size_t)(rec_group(r) - f_base) * TVP * 2;
+                    int vi[8];
+                    float qv[8];
 #pragma unroll
-        for (int j = 0; j < OVM; ++j) {
-            size_t g4;
-            const unsigned q = tid + j * NT;
-            if (elem_index(tile, q, g4)) map4[g4] = reinterpret_cast<const v4f *>(Dc)[q];
+                    for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
+                    for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+                    int vf = 0;
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) qv[cc] *= klow(cell, 2 * (vi[cc] >= 0 ? vi[cc] : vf));
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc)
+                        if (vi[cc] >= 0) {
+                            const float term = qv[cc];
+                            unsigned long long m = to_fixed(term, 182 - DENSE_FX);
+                            if (m == 0ull && term > 0.0f) m = 1ull;
+                            if (m != 0ull) atomicAdd(&Di[KIND == 0 ? vi[cc] : vi[cc] * C + (int)x], m);
+                        }
+                };
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int e = t_s + tid + j * NT;
+                    if (e >= ea && e < eb && (KIND == 0 || prex[j] < (uint32_t)C)) p3_record(pre[j], prex[j]);
+                }
+                for (int bb = max(ea, t_s + NT * EB); bb < eb; bb += NT * EB) {
+                    uint4 r[EB];
+                    uint32_t x[EB];
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) {
+                        const int e = min(bb + tid + j * NT, eb - 1);
+                        r[j] = P.rec[e];
+                        x[j] = KIND == 1 ? P.aux[e] : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < EB; ++j)
+                        if (bb + tid + j * NT < eb && (KIND == 0 || x[j] < (uint32_t)C)) p3_record(r[j], x[j]);
+                }
+            }
+            barrier_keep_vm();
+            MF_STAMP(4)
+            if (c == n_chunks - 1) {
+                if (tile_n >= 0) prefetch_entries(offs_n[0], offs_n[n_chunks], pre, prex);   // the next tile's first records
+                v4f oldv[OVM];
+#pragma unroll
+                for (int j = 0; j < OVM; ++j) {          // unconditional: an element outside the map reads element 0
+                    size_t g4;
+                    const bool in = elem_index(tile, tid + j * NT, g4);
+                    oldv[j] = map4[in ? g4 : 0];
+                }
+                // ---- the tile's rows go out: old * prod a + D (every row whole: an untouched voxel is rewritten
+                // with the value it had), and the deltas are cleared
+#pragma unroll
+                for (int j = 0; j < OVM; ++j) {
+                    size_t g4;
+                    const unsigned q = tid + j * NT;
+                    if (elem_index(tile, q, g4)) {
+                        const unsigned i = q << 2;
+                        unsigned long long *d = Di + i;
+                        v4f o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned v = div_magic(i + k, P.magicC);
+                            o[k] = oldv[j][k] * atot[v] + (float)d[k] * di_inv;
+                            d[k] = 0ull;
+                        }
+                        map4[g4] = o;
+                    }
+                }
+            }
+            for (int i = tid; i < nc * TVP * 2; i += NT) A[i] = 0ull;     // the chunk's cells
         }
         if (tile_n < 0) break;
-#pragma unroll
-        for (int j = 0; j < OVM; ++j) {
-            size_t g4;
-            const unsigned q = tid + j * NT;
-            if (elem_index(tile_n, q, g4)) reinterpret_cast<v4f *>(Dc)[q] = oldv[j];
-        }
-        {                                                // clear the cells this tile touched, and the masks
-            const int v = tid / PP, p = tid - v * PP;
-            if (v < TV) {
-                const int f0 = p * FP;
-                const unsigned long long all = mask[v];
-                const unsigned long long mine = FP >= 64 ? all : f0 >= 64 ? 0ull : (all >> f0) & ((1ull << FP) - 1ull);
-                for (unsigned long long m = mine; m; m &= m - 1ull) {
-                    unsigned long long *c = A + ((size_t)(f0 + __builtin_ctzll(m)) * TVP + v) * 2;
-                    c[0] = 0ull; c[1] = 0ull;
-                }
-                if (p == 0 && all) mask[v] = 0ull;
-            }
-        }
-        tile = tile_n; ts = ts_n; te = te_n;
-#pragma unroll
-        for (int j = 0; j < EB; ++j) { pre[j] = pre_n[j]; prex[j] = prex_n[j]; }
+        tile = tile_n;
+        if (tid <= n_chunks) offs[tid] = offs_n[tid];       // read by everyone after the next barrier ...
+        barrier_keep_vm();                                   // ... which is this one (offs is read before the chunk loop)
     }
     if (STAMPS && tid == 0) {
         unsigned long long tot = 0;
@@ -1693,22 +1692,81 @@ static int ilog2_floor(unsigned x) { int l = 0; while ((2u << l) <= x) ++l; retu
 // deltas + scales + flag + four frames of 64-bit W/S2 accumulators per voxel) fits the
 // CU's LDS, capped at 512 voxels (8 x 8 x 8); z gets up to 8 so that HBM runs stay long.
 // Tuning override for experiments: MF_TILE="s0 s1 s2 threads" (log2 extents).
-// fuse_sparse_kernel: G rows of (TV + 1) 16-byte cells, a mask per voxel, the tile image, a few words
-static size_t sparse_lds_bytes(int C, int sv, int G)
+// fuse_dense_kernel: gc rows of (TV + 1) 16-byte cells, 8-byte deltas, prod a per voxel, look-up words
+static size_t dense_lds_bytes(int C, int gc)
 {
-    const size_t TV = (size_t)1 << sv;
-    return (size_t)G * (TV + 1) * 16 + TV * 8 + TV * C * 4 + 16 * 4 + 16;
+    const size_t TV = (size_t)1 << DENSE_SV;
+    return (size_t)gc * (TV + 1) * 16 + TV * C * 8 + TV * 4 + (16 + 2 * (DENSE_MAX_CHUNKS + 2)) * 4 + 16;
 }
 
-// Calls of several sequential frames are bucketed on 4 x 4 x 8 tiles when the sparse variant of the tile
-// kernel could take them (whether it does is decided on the device, after counting): its cells for all the
-// frames and three tile images have to fit, with a few KB left for the bucketing kernels of the next batch.
-constexpr int SPARSE_SV = 7;
-static bool sparse_shape(const mf_grid *g, int G)
+// frames per chunk of fuse_dense_kernel: up to 32 within 128 KB of LDS (measured on the room batch: 8 frames
+// and two workgroups per CU 2.15 ms, 16: 2.10, 32: 2.04; the rest of the LDS is left to the bucketing
+// kernels of the next batch).  MF_DENSE_GC overrides.
+static int dense_chunk_frames(int C, int G)
 {
-    static const bool on = !(getenv("MF_SPARSE") && atoi(getenv("MF_SPARSE")) == 0);
-    return on && G > 2 && G <= SPARSE_MAX_GC && sparse_lds_bytes(g->channels, SPARSE_SV, G) <= 160 * 1024 &&
-           ((size_t)g->channels << SPARSE_SV) / 4 <= 4 * 512;          // the tile image in 4 float4 registers of 512 threads
+    static const int forced = getenv("MF_DENSE_GC") ? atoi(getenv("MF_DENSE_GC")) : 0;
+    int gc = forced > 0 ? forced : 32;
+    if (gc > 64) gc = 64;
+    if (gc > G) gc = G;
+    while (gc > 1 && dense_lds_bytes(C, gc) > (forced > 0 ? 160 : 128) * 1024) gc /= 2;
+    while ((G + gc - 1) / gc > DENSE_MAX_CHUNKS && gc < 64) gc *= 2;
+    return gc;
+}
+
+// May a call of G sequential frames onto this grid be bucketed on the 4 x 4 x 8 tiles of fuse_dense_kernel?
+// (its LDS image fits, the tile image fits the registers of 512 threads; the feature kind and the alignment
+// of the rows are checked when the kernel is launched: fuse_tiles_kernel works on any tile shape)
+static bool dense_shape_ok(const mf_grid *g, int G)
+{
+    static const bool on = !(getenv("MF_DENSE") && atoi(getenv("MF_DENSE")) == 0);
+    if (!on || G < 2) return false;
+    const int gc = dense_chunk_frames(g->channels, G);
+    return dense_lds_bytes(g->channels, gc) <= 160 * 1024 && (G + gc - 1) / gc <= DENSE_MAX_CHUNKS &&
+           ((size_t)g->channels << DENSE_SV) / 4 <= 4 * 512;
+}
+
+// What the previous call on a workspace counted decides the tile shape of the next one: the density of a
+// trajectory changes slowly, and the shape has to be fixed before the points are bucketed.  After its
+// tile_list_kernel a call copies two words (records, threshold) to pinned host memory; the next call on
+// the same workspace reads them if the copy has finished.  MF_DENSE=1 forces the dense shape, 0 forbids it.
+struct TileHint {
+    hipEvent_t ev = nullptr;
+    int *host = nullptr;
+    bool pending = false;
+    bool dense = false;        // what the last finished call measured
+    bool staged_dense = false; // shape of the batch staged last (a commit on its own must use the same)
+};
+static std::mutex g_hint_mu;
+static std::unordered_map<const void *, TileHint> g_hints;
+
+static bool tile_hint(const void *ws)
+{
+    static const int forced = getenv("MF_DENSE") ? atoi(getenv("MF_DENSE")) : -1;
+    if (forced == 1) return true;
+    if (forced == 0 || !ws) return false;
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    auto it = g_hints.find(ws);
+    if (it == g_hints.end()) return false;
+    TileHint &h = it->second;
+    if (h.pending && hipEventQuery(h.ev) == hipSuccess) {
+        h.pending = false;
+        h.dense = h.host[0] >= h.host[1] && h.host[0] > 0;
+    }
+    return h.dense;
+}
+
+static void tile_hint_post(const void *ws, const int *dev_words, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    TileHint &h = g_hints[ws];
+    if (!h.ev) {
+        if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) { h.ev = nullptr; return; }
+        if (hipHostMalloc((void **)&h.host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) { h.host = nullptr; return; }
+        h.host[0] = h.host[1] = 0;
+    }
+    if (!h.host || h.pending) return;            // one copy in flight at a time
+    if (hipMemcpyAsync(h.host, dev_words, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return;
+    if (hipEventRecord(h.ev, st) == hipSuccess) h.pending = true;
 }
 
 static int g_gc_override = -1;
@@ -1726,11 +1784,11 @@ static bool tile_override(int &s0, int &s1, int &s2, int &nt)
     return have;
 }
 
-static void choose_tile(const mf_grid *g, int n_groups, int &s0, int &s1, int &s2)
+static void choose_tile(const mf_grid *g, int n_groups, bool dense, int &s0, int &s1, int &s2)
 {
     int nt_unused;
     if (tile_override(s0, s1, s2, nt_unused)) return;
-    if (sparse_shape(g, n_groups)) { s0 = 2; s1 = 2; s2 = 3; return; }
+    if (dense && dense_shape_ok(g, n_groups)) { s0 = 2; s1 = 2; s2 = 3; return; }
     const size_t budget = 158 * 1024 - 8 * (MAX_GROUPS + 32) - 2 * MAX_GROUPS;
     size_t per_voxel = (size_t)g->channels * 4 + 8 + 1 + 4 * 16;      // deltas, scales, flag, >= 4 frames of W/S2
     unsigned tv = (unsigned)(budget / per_voxel);
@@ -1924,7 +1982,21 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (P.G < 1 || P.G > MAX_GROUPS)
         return fail(MF_ERR_INVALID, "at most %d sequential frames per call, got %d", MAX_GROUPS, P.G);
     if (P.n_points == 0) return MF_OK;
-    choose_tile(grid, P.G, P.s0, P.s1, P.s2);
+    // tile shape: 4 x 4 x 8 when the previous call on this workspace found the scene dense; a commit on its
+    // own takes what its staging call took
+    bool dense_tiles;
+    if (phase == 2) {
+        std::lock_guard<std::mutex> lock(g_hint_mu);
+        auto it = g_hints.find(workspace);
+        dense_tiles = it != g_hints.end() && it->second.staged_dense;
+    } else {
+        dense_tiles = FRONT == 0 && P.G >= 2 && tile_hint(workspace) && dense_shape_ok(grid, P.G);
+        if (FRONT == 0 && P.G >= 2) {
+            std::lock_guard<std::mutex> lock(g_hint_mu);
+            g_hints[workspace].staged_dense = dense_tiles;
+        }
+    }
+    choose_tile(grid, P.G, dense_tiles, P.s0, P.s1, P.s2);
     Layout L;
     if (!make_layout(grid, P.n_points, P.G, P.s0, P.s1, P.s2, L, P.nt0, P.nt1, P.nt2))
         return fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets (points %lld, groups %d)",
@@ -1972,15 +2044,20 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     int blocks = dev.cus * per_cu;
     { static const int cap = getenv("MF_BLOCKS") ? atoi(getenv("MF_BLOCKS")) : 0; if (cap > 0 && blocks > cap) blocks = cap; }   // dev: fewer workgroups
     if (blocks > P.n_tiles) blocks = P.n_tiles;
-    // sparse variant of the tile kernel (class ids / ones, several sequential frames, float4 rows, 4 x 4 x 8
-    // tiles): launched next to the tile kernel, tile_list_kernel decides on the device which of the two runs
-    static const int sparse_nt = getenv("MF_SPARSE_NT") ? atoi(getenv("MF_SPARSE_NT")) : 512;
-    const size_t slds_sparse = sparse_lds_bytes(P.C, sv, P.G);
-    const bool sparse = sparse_shape(grid, P.G) && sv == SPARSE_SV && P.s2 == 3 && P.feat_kind != MF_FEAT_DENSE_F32 &&
-                        P.vec4 && slds_sparse <= (size_t)dev.lds_per_cu;
-    int blocks_sparse = dev.cus * (int)((size_t)dev.lds_per_cu / (slds_sparse ? slds_sparse : 1));
-    { static const int cap = getenv("MF_BLOCKS") ? atoi(getenv("MF_BLOCKS")) : 0; if (cap > 0 && blocks_sparse > cap) blocks_sparse = cap; }
-    if (blocks_sparse > P.n_tiles) blocks_sparse = P.n_tiles;
+    // the all-integer tile kernel (class ids / ones, float4 rows, 4 x 4 x 8 tiles): launched next to the tile
+    // kernel when the call was bucketed on its tiles; tile_list_kernel decides on the device which of the two runs
+    static const int dense_nt = getenv("MF_DENSE_NT") ? atoi(getenv("MF_DENSE_NT")) : 512;
+    const int dgc = dense_chunk_frames(P.C, P.G);
+    const size_t dlds = dense_lds_bytes(P.C, dgc);
+    const bool use_dense = dense_tiles && sv == DENSE_SV && P.s2 == 3 && P.feat_kind != MF_FEAT_DENSE_F32 && P.vec4 &&
+                       dlds <= (size_t)dev.lds_per_cu && (P.G + dgc - 1) / dgc <= DENSE_MAX_CHUNKS;
+    const int dnt = dense_nt >= 1024 ? 1024 : 512;
+    int dper = (int)((size_t)dev.lds_per_cu / dlds);
+    if (dper > 2048 / dnt) dper = 2048 / dnt;
+    if (dper < 1) dper = 1;
+    int blocks_dense = dev.cus * dper;
+    { static const int cap = getenv("MF_BLOCKS") ? atoi(getenv("MF_BLOCKS")) : 0; if (cap > 0 && blocks_dense > cap) blocks_dense = cap; }
+    if (blocks_dense > P.n_tiles) blocks_dense = P.n_tiles;
 
     if (phase & 1) {
     prof_mark(0, st);
@@ -2004,8 +2081,9 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
                        P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
                        (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks,
-                       sparse ? SPARSE_MAX_MEAN : 0, 4 * blocks_sparse);
+                       use_dense ? (1 << sv) : 0, 4 * blocks_dense);
     MF_LAUNCH_CHECK("tile_list_kernel");
+    if (FRONT == 0 && P.G >= 2 && phase != 2) tile_hint_post(workspace, P.ticket + HINT_SLOT, st);
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
@@ -2049,27 +2127,26 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);      // returns at once when the call went to the single-pass kernel
     MF_LAUNCH_CHECK("fuse_tiles_kernel");
-    if (sparse) {
-        const int snt = sparse_nt >= 1024 ? 1024 : 512;
-        void (*sk)(TileParams);
-        if (snt >= 1024) sk = stamps ? (kind == 0 ? fuse_sparse_kernel<0, 1024, true> : fuse_sparse_kernel<1, 1024, true>)
-                                     : (kind == 0 ? fuse_sparse_kernel<0, 1024> : fuse_sparse_kernel<1, 1024>);
-        else sk = stamps ? (kind == 0 ? fuse_sparse_kernel<0, 512, true> : fuse_sparse_kernel<1, 512, true>)
-                         : (kind == 0 ? fuse_sparse_kernel<0, 512> : fuse_sparse_kernel<1, 512>);
+    if (use_dense) {
+        void (*dk)(TileParams);
+        if (dnt >= 1024) dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 1024, true> : fuse_dense_kernel<1, 1024, true>)
+                                     : (kind == 0 ? fuse_dense_kernel<0, 1024> : fuse_dense_kernel<1, 1024>);
+        else dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 512, true> : fuse_dense_kernel<1, 512, true>)
+                         : (kind == 0 ? fuse_dense_kernel<0, 512> : fuse_dense_kernel<1, 512>);
         {
             static std::mutex mu3;
             static std::unordered_map<const void *, size_t> granted3;
             std::lock_guard<std::mutex> lock(mu3);
-            size_t &have = granted3[(const void *)sk];
-            if (have < slds_sparse) {
-                MF_HIP_CHECK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds_sparse));
-                have = slds_sparse;
+            size_t &have = granted3[(const void *)dk];
+            if (have < dlds) {
+                MF_HIP_CHECK(hipFuncSetAttribute((const void *)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                have = dlds;
             }
         }
         TileParams S = T;
-        { static const int dbg = getenv("MF_DBG") ? atoi(getenv("MF_DBG")) : 0; S.vec4 |= dbg << 8; }
-        hipLaunchKernelGGL(sk, dim3(blocks_sparse), dim3(snt), slds_sparse, st, S);   // returns at once unless tile_list_kernel chose it
-        MF_LAUNCH_CHECK("fuse_sparse_kernel");
+        S.gc = dgc;
+        hipLaunchKernelGGL(dk, dim3(blocks_dense), dim3(dnt), dlds, st, S);   // returns at once unless tile_list_kernel chose it
+        MF_LAUNCH_CHECK("fuse_dense_kernel");
     }
     if (single) {
         SingleParams S;
@@ -2112,8 +2189,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         fprintf(stderr, "[MF_STAMPS] blocks=%d nt=%d lds=%zu gc=%d | ticket+offs %.1f%% setup %.1f%% chunk-zero %.1f%% P1 %.1f%% P2 %.1f%% P3 %.1f%% final %.1f%% | total %.3g ticks/block\n",
                 blocks, nt, lds, P.gc, 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot,
                 100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot, tot / blocks);
-        if (z[7]) fprintf(stderr, "[MF_STAMPS] sparse kernel: %d workgroups, mean %.3g ticks, slowest %.3g | look-ups %.1f%% zero %.1f%% pass1 %.1f%% wait %.1f%% out+in issue %.1f%% pass2 %.1f%% pass3 %.1f%%\n", blocks_sparse,
-                          tot / blocks_sparse, (double)z[7], 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[6] / tot, 100 * z[2] / tot, 100 * z[5] / tot, 100 * z[3] / tot, 100 * z[4] / tot);
+        if (z[7]) fprintf(stderr, "[MF_STAMPS] dense kernel: %d workgroups, gc %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% barrier %.1f%% pass1 %.1f%% look-ups+barrier %.1f%% fetch issue %.1f%% pass2 %.1f%% pass3 %.1f%%\n", blocks_dense, dgc,
+                          tot / blocks_dense, (double)z[7], 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[6] / tot, 100 * z[2] / tot, 100 * z[5] / tot, 100 * z[3] / tot, 100 * z[4] / tot);
     }
     return MF_OK;
 }
@@ -2157,14 +2234,19 @@ size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int32_t n_
         fail(MF_ERR_INVALID, "n_points must be >= 0 and n_groups in [1, %d]", MAX_GROUPS);
         return 0;
     }
-    int s0, s1, s2, a, b, c;
-    choose_tile(grid, n_groups, s0, s1, s2);
-    Layout L;
-    if (!make_layout(grid, n_points, n_groups, s0, s1, s2, L, a, b, c)) {
-        fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets");
-        return 0;
+    // whichever tile shape a call takes (it depends on what the previous call measured): the larger layout
+    size_t need = 0;
+    for (int dense = 0; dense < 2; ++dense) {
+        int s0, s1, s2, a, b, c;
+        choose_tile(grid, n_groups, dense != 0, s0, s1, s2);
+        Layout L;
+        if (!make_layout(grid, n_points, n_groups, s0, s1, s2, L, a, b, c)) {
+            fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets");
+            return 0;
+        }
+        if (L.total > need) need = L.total;
     }
-    return L.total;
+    return need;
 }
 
 int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight, int32_t mode,
