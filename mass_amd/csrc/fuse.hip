@@ -193,7 +193,7 @@ __device__ __forceinline__ int point_keys(const FuseParams &P, const Point &pt, 
 // ----------------------------------------------------------------------------
 // per-block LDS hash: bucket key -> (count, base)
 // ----------------------------------------------------------------------------
-constexpr int TILE_CLASSES = 4;          // load classes of the tile work list (tile_list_kernel)
+constexpr int TILE_CLASSES = 8;          // load classes of the tile work list (tile_list_kernel)
 constexpr int ABORT_SLOT = 1 + TILE_CLASSES;   // ticket[ABORT_SLOT] != 0: a class id was out of range, the call is called off
 constexpr int BIN_THREADS = 256;
 constexpr int HS_BITS = 8;
@@ -328,11 +328,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int *data, int
     int run = pre + woff + inc - s;
     int filled = 0;
     for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) { data[base + i] = run; run += v[i]; filled += v[i] > 0; }
-    if (nonempty) {
-        const unsigned long long m = __ballot(filled > 0);
-        if (m) {                                        // few blocks see anything at all in a single-frame call
-            for (int o = 32; o > 0; o >>= 1) filled += __shfl_down(filled, o, 64);
-            if (lane == 0 && filled) atomicAdd(nonempty, filled);
+    if (nonempty) {                                     // one atomic per block (all of them land on one word)
+        for (int o = 32; o > 0; o >>= 1) filled += __shfl_down(filled, o, 64);
+        __syncthreads();
+        if (lane == 0) wsum[wid] = filled;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < SCAN_THREADS / 64; ++w) t += wsum[w];
+            if (t) atomicAdd(nonempty, t);
         }
     }
 }
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int *data, int
 
 __device__ __forceinline__ int tile_class(int n)
 {
-    return n >= 8192 ? 0 : n >= 2048 ? 1 : n >= 512 ? 2 : 3;
+    return n >= 131072 ? 0 : n >= 65536 ? 1 : n >= 32768 ? 2 : n >= 16384 ? 3 : n >= 8192 ? 4 : n >= 2048 ? 5 : n >= 512 ? 6 : 7;
 }
 
 // Work items of fuse_single_kernel (single-group calls with class-id / ones features, split_min > 0):
@@ -567,8 +571,8 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     float *osc = sc + TV;                          // [TV] prod a_f: factor of the old map value
     int *offs2 = (int *)(osc + TV);                // [2][MAX_GROUPS + 1] bucket starts: this tile / next tile
     int *cb = offs2 + 2 * (MAX_GROUPS + 1);        // [MAX_CHUNK + 1] entry offsets of the chunk's frames
-    int *misc = cb + MAX_CHUNK + 1;                // [0] first tile, [1] non-empty frame count, [2] tile after next, [3] second tile, [4..7] class sizes
-    unsigned short *ne = (unsigned short *)(misc + 8);   // [MAX_GROUPS] non-empty frames, ascending
+    int *misc = cb + MAX_CHUNK + 1;                // [0] first tile, [1] non-empty frame count, [2] tile after next, [3] second tile, [4..] class sizes
+    unsigned short *ne = (unsigned short *)(misc + 4 + TILE_CLASSES);   // [MAX_GROUPS] non-empty frames, ascending
     unsigned char *touched = (unsigned char *)(ne + MAX_GROUPS);   // [TV]
     const int G = P.G;
     const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
@@ -613,7 +617,12 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     // loads issued one tile earlier costs no wait of its own (vmcnt retires in order: waiting for an
     // old load at any other point would also wait for every younger load and store of the wave).
     if (P.ticket[MODE_SLOT] != 0) return;                                        // fuse_dense_kernel takes the call (uniform)
-    if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;      // nothing listed (uniform)
+    {
+        int listed = 0;
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) listed += P.ticket[1 + c];
+        if (listed == 0) return;                                                 // nothing listed (uniform)
+    }
     // The first four work items of a workgroup are dealt statically, list positions b, b + n, b + 2n,
     // b + 3n for workgroup b of n: the list is heaviest first, so every workgroup starts on one of the
     // n heaviest tiles (four tickets drawn in a row would hand the four heaviest to one workgroup).
@@ -961,7 +970,8 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
     unsigned long long *A = reinterpret_cast<unsigned long long *>(smem);      // [GC][TV + 1][2] W, S2; low word of W = t_f after pass 2
     unsigned long long *Di = A + (size_t)GC * TVP * 2;                         // [TV][C] deltas, units of 2^-DENSE_FX
     float *atot = reinterpret_cast<float *>(Di + n_el);                        // [TV] prod a over the frames so far
-    int *misc = reinterpret_cast<int *>(atot + TV);                            // [0] tile, [4..7] class sizes, [8] next tile
+    int *misc = reinterpret_cast<int *>(atot + TV);                            // [0] tile, [4..] class sizes, [NEXT] next tile
+    constexpr int NEXT = 4 + TILE_CLASSES;
     int *offs = misc + 16;                                                     // [n_chunks + 1] record offsets of this tile's chunks
     int *offs_n = offs + DENSE_MAX_CHUNKS + 2;                                 // the next tile's
     const int fx_c = 182 - P.fx_shift;
@@ -969,7 +979,12 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
     const float di_inv = __uint_as_float((unsigned)(127 - DENSE_FX) << 23);    // 2^-DENSE_FX
 
     if (P.ticket[MODE_SLOT] != 2) return;                                      // another tile kernel takes the call (uniform)
-    if (P.ticket[1] + P.ticket[2] + P.ticket[3] + P.ticket[4] == 0) return;
+    {
+        int listed = 0;
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) listed += P.ticket[1 + c];
+        if (listed == 0) return;
+    }
 
     auto resolve = [&](int idx) {          // work list position -> tile id, -1 past the end
         int tile_id = -1;
@@ -1089,7 +1104,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
             }
             MF_STAMP(6)
             if (c == 0 && tid < 64) {                    // advance the look-ups
-                if (tid == 0) misc[8] = nx_tile;
+                if (tid == 0) misc[NEXT] = nx_tile;
                 if (tid <= n_chunks) offs_n[tid] = nx_off;
                 nx_tile = rng_tile; nx_off = rng_off;
                 rng_tile = act_pend;
@@ -1101,7 +1116,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
             barrier_keep_vm();
             MF_STAMP(2)
 
-            if (c == 0) tile_n = misc[8];
+            if (c == 0) tile_n = misc[NEXT];
             MF_STAMP(5)
 
             // ---- pass 2: per voxel t_f = g_f * prod_{f' > f} a_f' into the cells; prod a over the chunk
@@ -1809,7 +1824,7 @@ static void choose_tile(const mf_grid *g, int n_groups, bool dense, int &s0, int
 static size_t tile_lds_fixed(int C, int sv)
 {
     const size_t TV = (size_t)1 << sv;
-    return TV * C * 4 + TV * 8 + 2 * (MAX_GROUPS + 1) * 4 + (MAX_CHUNK + 1) * 4 + 8 * 4 + MAX_GROUPS * 2 + TV + 16;
+    return TV * C * 4 + TV * 8 + 2 * (MAX_GROUPS + 1) * 4 + (MAX_CHUNK + 1) * 4 + (4 + TILE_CLASSES) * 4 + MAX_GROUPS * 2 + TV + 16;
 }
 
 // frames per chunk: what fits next to the tile's deltas, at most 64 KB of accumulators
