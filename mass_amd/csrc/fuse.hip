@@ -76,6 +76,7 @@ struct FuseParams {
     int *active;               // [TILE_CLASSES][n_tiles]
     uint4 *rec;
     uint32_t *aux;
+    uint4 *pts;                // [n_points] (front end 0) the binned pixels, written by count_kernel for scatter_kernel
 };
 
 // What the tile kernel needs (a subset: fewer scalar registers held across its loop).
@@ -211,6 +212,19 @@ __device__ __forceinline__ int hash_insert(uint32_t *hkey, int *hcnt, uint32_t k
     return -1;
 }
 
+// The 16-byte record of a binned point: 10 + 10 + 10 voxel index bits and the three ratios.  The group
+// (frame) rides in the two top bits of the four words: a ratio in [0, 1] has its sign and top exponent bit
+// clear (MAX_GROUPS = 256 = 8 bits).
+__device__ __forceinline__ uint4 make_record(const Point &pt)
+{
+    uint4 r;
+    r.x = (uint32_t)pt.k0 | ((uint32_t)pt.k1 << 10) | ((uint32_t)pt.k2 << 20);
+    r.y = __float_as_uint(pt.r0); r.z = __float_as_uint(pt.r1); r.w = __float_as_uint(pt.r2);
+    const uint32_t g = (uint32_t)pt.group;
+    r.x |= (g & 3u) << 30; r.y |= ((g >> 2) & 3u) << 30; r.z |= ((g >> 4) & 3u) << 30; r.w |= ((g >> 6) & 3u) << 30;
+    return r;
+}
+
 template <int FRONT>
 __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
 {
@@ -225,6 +239,11 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
         if (P.label_status && P.feat_kind >= MF_FEAT_LABEL_U8 && P.feat_kind <= MF_FEAT_LABEL_I64 && aux >= (uint32_t)P.C) {
             *P.label_status = 1;                        // reported to the host ...
             P.ticket[ABORT_SLOT] = 1;                   // ... and the rest of the pipeline is called off
+        }
+        if (FRONT == 0) {                               // scatter_kernel takes the binned pixel from here (no second unprojection)
+            uint4 r = make_record(pt);
+            if (!ok) r.y = 0xffffffffu;                // no ratio in [0, 1] has these low 30 bits
+            P.pts[idx] = r;
         }
         if (ok) {
             uint32_t keys[8];
@@ -252,7 +271,28 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
     uint32_t keys[8];
     int slot[8], rank[8];
     int n = 0;
-    if (idx >= 0 && get_point<FRONT>(P, idx, pt, aux)) {
+    uint4 r = make_uint4(0u, 0xffffffffu, 0u, 0u);
+    bool ok = false;
+    if (FRONT == 0) {
+        if (idx >= 0) r = P.pts[idx];
+        ok = (r.y & 0x3fffffffu) != 0x3fffffffu;
+        if (ok) {
+            const unsigned rm = 0x3fffffffu;
+            pt.k0 = r.x & 1023; pt.k1 = (r.x >> 10) & 1023; pt.k2 = (r.x >> 20) & 1023;
+            pt.r0 = __uint_as_float(r.y & rm); pt.r1 = __uint_as_float(r.z & rm); pt.r2 = __uint_as_float(r.w & rm);
+            pt.group = P.G == 1 ? 0 : (int)blockIdx.y;
+            if (P.feat_kind != MF_FEAT_ONES) {
+                const int pix = (int)(idx - (long long)blockIdx.y * (P.H * P.W));
+                const int y = pix / P.W, x = pix - y * P.W;
+                const long long fi = ((long long)blockIdx.y * P.fh + y / P.rep_y) * P.fw + x / P.rep_x;
+                aux = P.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)fi : read_label(P.feat, P.feat_kind, fi);
+            }
+        }
+    } else {
+        ok = idx >= 0 && get_point<FRONT>(P, idx, pt, aux);
+        if (ok) r = make_record(pt);
+    }
+    if (ok) {
         n = point_keys(P, pt, keys);
         for (int i = 0; i < n; ++i) slot[i] = hash_insert(hkey, hcnt, keys[i], rank[i]);
     }
@@ -262,13 +302,6 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
         if (hkey[s] != EMPTY) hcnt[s] = atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
     __syncthreads();
     if (n > 0) {
-        uint4 r;
-        r.x = (uint32_t)pt.k0 | ((uint32_t)pt.k1 << 10) | ((uint32_t)pt.k2 << 20);
-        r.y = __float_as_uint(pt.r0); r.z = __float_as_uint(pt.r1); r.w = __float_as_uint(pt.r2);
-        // the group (frame) rides in the two top bits of the four words: 10 + 10 + 10 index bits leave two,
-        // and a ratio in [0, 1] has its sign and top exponent bit clear (MAX_GROUPS = 256 = 8 bits)
-        const uint32_t g = (uint32_t)pt.group;
-        r.x |= (g & 3u) << 30; r.y |= ((g >> 2) & 3u) << 30; r.z |= ((g >> 4) & 3u) << 30; r.w |= ((g >> 6) & 3u) << 30;
         for (int i = 0; i < n; ++i) {
             const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
             P.rec[pos] = r;
@@ -794,14 +827,48 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             MF_STAMP(4)
             // pass 3: D += k_f * w^2 * feat
             if (KIND == 0 || KIND == 1) {
+                // The adds of a record's corners go in rounds of four (k reads, reads of the current sums,
+                // compare-and-swaps, float atomics of the lanes that lost a race) with NO branch between the LDS
+                // operations of a round: the wait counters are only tracked exactly inside a basic block, so a
+                // corner outside the tile goes through the motions on the word of one that is inside, with a
+                // compare value that makes the swap a no-op.  (Dense scenes, where back-to-back swaps of a wave
+                // collide, are taken by fuse_dense_kernel.)
                 auto add = [&](int e, const uint4 &r, uint32_t label) {
+                    if (KIND == 1 && label >= (uint32_t)C) return;
                     const int base = slot_of(e) * TV;
-                    if (KIND == 0)
-                        for_corners(P, r, o0, o1, o2, [&](int v, float w) { lds_add_f32(&D[v], (w * w) * klow(W64, base + v)); });
-                    else if (label < (uint32_t)C)
-                        for_corners(P, r, o0, o1, o2, [&](int v, float w) {
-                            lds_add_f32(&D[v * C + label], (w * w) * klow(W64, base + v));
-                        });
+                    unsigned *Du = reinterpret_cast<unsigned *>(D);
+                    int vi[8];
+                    float qv[8];
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
+                    for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+                    int vf = 0;
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
+#pragma unroll
+                    for (int h = 0; h < 8; h += 4) {
+                        unsigned seen[4], prev[4];
+                        int a[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a[i] = vi[h + i] >= 0 ? vi[h + i] : vf;
+                            qv[h + i] *= klow(W64, base + a[i]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a[i] = KIND == 0 ? a[i] : a[i] * C + (int)label;
+                            seen[i] = Du[a[i]];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool on = vi[h + i] >= 0;
+                            prev[i] = atomicCAS(&Du[a[i]], on ? seen[i] : 0xffffffffu,
+                                                on ? __float_as_uint(__uint_as_float(seen[i]) + qv[h + i]) : 0xffffffffu);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (vi[h + i] >= 0 && prev[i] != seen[i]) atomicAdd(&D[a[i]], qv[h + i]);
+                    }
                 };
                 for (int bb = bb0; bb < eb; bb += NT * EB) {
                     uint4 r[EB];
@@ -1850,7 +1917,7 @@ static size_t tile_lds_bytes(int C, int sv, int gc)
 }
 
 struct Layout {
-    size_t cursor, block_sums, ticket, slot_count, slot_ws, slot_u, slot_bits, active, items, rec, aux, total;
+    size_t cursor, block_sums, ticket, slot_count, slot_ws, slot_u, slot_bits, active, items, rec, aux, pts, total;
     int n_keys, n_scan_blocks;
     int split_slots, split_items;      // 0: no split tiles (sequential groups, or MF_SPLIT=0)
     long long cap;
@@ -1911,6 +1978,7 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
     L.items = off; off = align_up(off + (size_t)L.split_items * 8, 256);
     L.rec = off; off = align_up(off + (size_t)cap * 16, 256);
     L.aux = off; off = align_up(off + (size_t)cap * 4, 256);
+    L.pts = off; off = align_up(off + (size_t)n_points * 16, 256);      // binned pixels, count -> scatter
     L.total = off;
     return true;
 }
@@ -2025,6 +2093,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     P.ticket = (int *)(ws + L.ticket);
     P.active = (int *)(ws + L.active);
     P.rec = (uint4 *)(ws + L.rec);
+    P.pts = (uint4 *)(ws + L.pts);
     P.aux = (uint32_t *)(ws + L.aux);
     P.n_tiles = P.nt0 * P.nt1 * P.nt2;
     P.n_keys = L.n_keys;
