@@ -19,7 +19,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof")
+src = os.environ.get("MF_PROFILE_SRC") or os.path.join(ROOT, "gpurun_out", "prof")
+fuse_kernel = os.environ.get("MF_PROFILE_KERNEL", "mf::fuse_tiles_kernel")   # the tile kernel that did the work
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 workload_key = sys.argv[2] if len(sys.argv) > 2 else "distA_sequential_b64"
 out_dir = os.environ.get("MF_PROFILE_OUT") or os.path.join(ROOT, "profiles")
@@ -101,7 +102,7 @@ tfile = os.path.join(out_dir, "traffic.json")
 traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
 if traffic.get("kernel_sources_sha16") != bench.sources_sha():
     traffic = {}                       # measured on other kernel sources: start over
-fuse = [v for k, v in summary.items() if k.startswith("mf::fuse_tiles_kernel")]
+fuse = [v for k, v in summary.items() if k.startswith(fuse_kernel)]
 traffic["kernel_sources_sha16"] = bench.sources_sha()
 traffic[workload_key] = fuse[0]["hbm_bytes_per_launch"] if fuse else None
 traffic[workload_key + "_pipeline"] = total
