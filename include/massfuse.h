@@ -138,7 +138,14 @@ MF_API size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int
  * update_feature_map, and the one_hot / ones_like front ends of
  * semantic_projection_layer.py:203-214 / occupancy_projection_layer.py:159-161).
  * Updates grid->map in place.  n_frames <= 256 per call.
- * The workspace needs no initialisation and holds nothing between calls. */
+ * The workspace needs no initialisation and holds nothing between calls.
+ * A call of several sequential frames picks its map-tile shape (8x8x8, or 4x4x8 with
+ * the all-integer tile kernel for real scenes) from the point density the PREVIOUS call
+ * with the same workspace pointer measured: two words are copied to pinned host memory
+ * behind the call and read, without waiting, at the start of the next one (per
+ * workspace the library keeps one event and 8 pinned bytes; MF_DENSE=0/1 in the
+ * environment pins the choice).  The result does not depend on the choice beyond the
+ * stated tolerance. */
 MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
                    int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
 
