@@ -726,20 +726,22 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             // too, the final pass becomes write-only, and the 110 KB read overlaps pass 1.
             // One wave instruction moves 64 x 16 B = 1 KB; the LDS side is linear, the global
             // side is per lane (tile rows of T2*C floats are contiguous in the map).
-            const unsigned n4 = n_el >> 2, row_len = (unsigned)C << P.s2;
-            for (unsigned q0 = (unsigned)(tid & ~63); q0 < n4; q0 += NT) {
-                const unsigned q = q0 + (tid & 63);
-                if (q < n4) {
-                    const unsigned i = q << 2;
-                    const unsigned r = div_magic(i, P.magicC) >> P.s2;     // row = (l0, l1)
-                    const int l1 = r & m1, l0 = r >> P.s1;
-                    if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
-                        const float *g = P.map + ((((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C +
-                                                  (i - r * row_len));
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void *)g,
-                            (__attribute__((address_space(3))) void *)(D + ((size_t)q0 << 2)), 16, 0, 0);
-                    }
+            // A wave takes whole rows (row, wave and the row's address are scalars: the address arithmetic
+            // runs on the scalar unit; measured before this, 6,912 float4s per tile each with its own divide
+            // and 64-bit address made the preload and the final pass VALU-bound, not memory-bound).
+            const unsigned row_len = (unsigned)C << P.s2, row4 = row_len >> 2;
+            const int n_rows = TV >> P.s2, NW = NT >> 6;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            for (int r = wave; r < n_rows; r += NW) {
+                const int l1 = r & m1, l0 = r >> P.s1;
+                if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
+                    const float *grow = P.map + (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C;
+                    float *drow = D + (size_t)r * row_len;
+                    for (unsigned f0 = 0; f0 < row4; f0 += 64)
+                        if (f0 + lane < row4)
+                            __builtin_amdgcn_global_load_lds(
+                                (const __attribute__((address_space(1))) void *)(grow + ((f0 + lane) << 2)),
+                                (__attribute__((address_space(3))) void *)(drow + (f0 << 2)), 16, 0, 0);
                 }
             }
         } else {
@@ -935,23 +937,31 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
         // float4 that straddles a touched and an untouched voxel rewrites the latter unchanged
         // (s = prod a = 1, D = 0), which is safe because the whole box belongs to this tile.
         if (P.vec4) {
-            // D already contains the old values (preloaded above): true = s * D, store only
-            const unsigned row_len = (unsigned)C << P.s2;          // floats per tile row
-            const unsigned n4 = n_el >> 2;
-            float4 *map4w = reinterpret_cast<float4 *>(P.map);
-            for (unsigned q = tid; q < n4; q += NT) {
-                const unsigned i = q << 2;
-                const unsigned v0 = div_magic(i, P.magicC), v3 = div_magic(i + 3, P.magicC);
-                const unsigned v1 = C < 3 ? div_magic(i + 1, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 1, P.magicC));
-                const unsigned v2 = C < 3 ? div_magic(i + 2, P.magicC) : (v0 == v3 ? v0 : div_magic(i + 2, P.magicC));
-                const unsigned r = v0 >> P.s2;                 // row = (l0, l1)
+            // D already contains the old values (preloaded above): true = s * D, store only; a wave takes
+            // whole rows, as in the preload
+            const unsigned row_len = (unsigned)C << P.s2, row4 = row_len >> 2;
+            const int n_rows = TV >> P.s2, NW = NT >> 6, T2 = 1 << P.s2;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            for (int r = wave; r < n_rows; r += NW) {
                 const int l1 = r & m1, l0 = r >> P.s1;
                 if (o0 + l0 < P.size0 && o1 + l1 < P.size1) {
-                    const size_t g = (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len);
-                    const float4 d = *reinterpret_cast<const float4 *>(D + i);
-                    float4 o;
-                    o.x = sc[v0] * d.x; o.y = sc[v1] * d.y; o.z = sc[v2] * d.z; o.w = sc[v3] * d.w;
-                    map4w[g >> 2] = o;
+                    float4 *grow4 = reinterpret_cast<float4 *>(P.map + (((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C);
+                    const float *drow = D + (size_t)r * row_len;
+                    const float *srow = sc + r * T2;
+                    for (unsigned f0 = 0; f0 < row4; f0 += 64) {
+                        const unsigned f4 = f0 + lane;
+                        if (f4 < row4) {
+                            const unsigned i = f4 << 2;                    // float index inside the row
+                            const unsigned v0 = div_magic(i, P.magicC), rem = i - v0 * C;
+                            unsigned v1, v2, v3;                           // voxels of the other three floats
+                            if (C >= 4) { v1 = v0 + (rem + 1 >= (unsigned)C); v2 = v0 + (rem + 2 >= (unsigned)C); v3 = v0 + (rem + 3 >= (unsigned)C); }
+                            else { v1 = div_magic(i + 1, P.magicC); v2 = div_magic(i + 2, P.magicC); v3 = div_magic(i + 3, P.magicC); }
+                            const float4 d = *reinterpret_cast<const float4 *>(drow + i);
+                            float4 o;
+                            o.x = srow[v0] * d.x; o.y = srow[v1] * d.y; o.z = srow[v2] * d.z; o.w = srow[v3] * d.w;
+                            grow4[f4] = o;
+                        }
+                    }
                 }
             }
         } else {
