@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 2
+#define MF_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define MF_API __attribute__((visibility("default")))
@@ -218,6 +218,12 @@ MF_API int mf_roi_moments(const float *map, int32_t size0, int32_t size1, int32_
  * Process-wide, not thread safe; off by default. */
 MF_API int mf_profile_enable(int32_t on);
 MF_API int mf_profile_read(int32_t call, float *ms /* [5] host */);
+
+/* What the next multi-frame call with this workspace pointer will be bucketed on, as far as
+ * the calls before it are known to have finished (see mf_fuse_frames): 1 = 4x4x8 tiles and
+ * the all-integer tile kernel (the last finished call found a real scene), 0 = 8x8x8 tiles.
+ * Never waits.  Used by the tests to prove which path ran. */
+MF_API int mf_fuse_tile_hint(const void *workspace);
 
 /* ---- matching (experimentation.py:261-265, 277-280, 284-287) --------------- */
 

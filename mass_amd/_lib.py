@@ -20,7 +20,7 @@ FEAT_ONES, FEAT_LABEL_U8, FEAT_LABEL_I32, FEAT_LABEL_I64, FEAT_DENSE_F32 = 0, 1,
 MODE_SEQUENTIAL, MODE_MERGED = 0, 1
 METRIC_L2, METRIC_L2_GEMM, METRIC_COSINE = 0, 1, 2
 MAX_FRAMES_PER_CALL = 256
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_float, ctypes.c_size_t)
@@ -70,6 +70,7 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "mf_profile_enable": (ctypes.c_int, [c_int32]),
     "mf_profile_read": (ctypes.c_int, [c_int32, c_void_p]),
+    "mf_fuse_tile_hint": (ctypes.c_int, [c_void_p]),
     "mf_pairwise_distance": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,
                                             c_int32, c_void_p]),
     "mf_linear_sum_assignment": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

@@ -2324,6 +2324,8 @@ int mf_profile_read(int32_t call, float *ms)
     return g_prof_calls;
 }
 
+int mf_fuse_tile_hint(const void *workspace) { return tile_hint(workspace) ? 1 : 0; }
+
 size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int32_t n_groups)
 {
     if (check_grid(grid, false) != MF_OK) return 0;

@@ -1,0 +1,76 @@
+"""Real-scene batches (SURVEY 8(d) distribution B): the all-integer tile kernel on 4x4x8 tiles.
+
+A multi-frame call picks its tile shape from the density the previous call on the same workspace
+measured (include/massfuse.h, mf_fuse_frames), so the second batch of a room trajectory runs in
+fuse_dense_kernel.  Both batches are checked against the oracle loop of layer.update() calls
+(base_projection_layer.py:282-343); the oracle is the C restatement pinned by the reference's fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_map_close
+
+pytestmark = pytest.mark.gpu
+H, W, MAP, C = 120, 160, 96, 7
+
+
+def _layers(device, kind):
+    from oracle import massref as orc
+    from mass_amd.nn.applications.occupancy_projection_layer import OccupancyProjectionLayer
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    kw = dict(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP, grid_resolution=0.08,
+              interpolation_weight=0.5)
+    if kind == "ones":
+        return OccupancyProjectionLayer(**kw).train().to(device), orc.RefProjectionLayer(feature_size=1, **kw)
+    return (SemanticProjectionLayer(feature_size=C, **kw).train().to(device),
+            orc.RefProjectionLayer(feature_size=C, **kw))
+
+
+@pytest.mark.parametrize("kind", ["label", "ones"])
+def test_room_batches_take_the_dense_kernel_and_match_the_oracle(device, kind):
+    from mass_amd import _lib
+    from mass_amd.episodes import room_trajectory
+    n = 12
+    tr = room_trajectory(2 * n, H, W, seed=3, num_classes=C)
+    lay, ref = _layers(device, kind)
+    for half in range(2):
+        sl = slice(half * n, (half + 1) * n)
+        batch = dict(position=tr["position"][sl], yaw=tr["yaw"][sl], elevation=tr["elevation"][sl],
+                     depth=tr["depth"][sl])
+        if kind == "label":
+            batch["semantic"] = tr["semantic"][sl]
+        lay.update_batch(batch, sequential=True)
+        torch.cuda.synchronize()                         # the density words of this call have reached the host
+        for t in range(sl.start, sl.stop):
+            feats = (torch.nn.functional.one_hot(tr["semantic"][t].long(), C).float() if kind == "label"
+                     else torch.ones(H, W, 1))
+            ref.update(dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t],
+                            depth=tr["depth"][t], features=feats))
+        assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"{kind} batch {half}")
+        wptr, _ = lay._workspace.get(1, lay.data.device)
+        hint = _lib.lib.mf_fuse_tile_hint(wptr)
+        assert hint == 1, "a room batch is dense: the next call on this workspace takes the 4x4x8 tiles"
+
+
+def test_dense_kernel_is_run_to_run_identical(device):
+    """Integer sums only (W, S2 and the deltas are 64-bit fixed point): the same batch twice gives the same bits."""
+    from mass_amd import _lib
+    from mass_amd.episodes import room_trajectory
+    tr = room_trajectory(16, H, W, seed=5, num_classes=C)
+    lay, _ref = _layers(device, "label")
+
+    def run(sl):
+        lay.update_batch(dict(position=tr["position"][sl], yaw=tr["yaw"][sl], elevation=tr["elevation"][sl],
+                              depth=tr["depth"][sl], semantic=tr["semantic"][sl]), sequential=True)
+        torch.cuda.synchronize()
+
+    run(slice(0, 8))                                     # measures the density: the next calls take the dense path
+    wptr, _ = lay._workspace.get(1, lay.data.device)
+    assert _lib.lib.mf_fuse_tile_hint(wptr) == 1
+    outs = []
+    for _ in range(2):
+        lay.reset()
+        run(slice(8, 16))
+        outs.append(lay.data.clone())
+    assert bool((outs[0] != 0).any())
+    assert torch.equal(outs[0], outs[1])
