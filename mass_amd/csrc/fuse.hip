@@ -15,24 +15,31 @@
 //   1. count     : every pixel is unprojected and binned (bit-exact integer path), its 2x2x2
 //                  footprint is mapped to the <= 8 tiles it overlaps, and (tile, frame) bucket
 //                  sizes are counted through a per-block LDS hash, so a block issues one global
-//                  integer atomic per distinct bucket (blocks own 16 x 16 pixel patches);
-//   2. scan      : exclusive prefix sum of the bucket sizes; list of non-empty tiles, heaviest
-//                  load class first;
-//   3. scatter   : the same geometry again, now writing a 20-byte point record into its
-//                  bucket slot (slot = bucket base + LDS-local rank);
-//   4. fuse_tiles: persistent workgroups walk the tile list (ticket counter; the next tile's
-//                  ticket, id, offsets and first records are fetched one tile ahead).  The
-//                  tile's old map values are preloaded into LDS by LDS-DMA while pass 1 runs;
-//                  frames are taken in chunks: pass 1 accumulates W, S2 as 64-bit fixed-point
-//                  LDS integer atomics (ds_add_f32 is 29x slower than ds_add_u32 on gfx950),
-//                  pass 2 turns them into k_f = g_f / s_f per voxel, pass 3 adds w^2 k_f feat
-//                  (one compare-and-swap, float atomic only on a lost race); the final pass
-//                  writes s * D for every touched voxel, as float4, exactly once per call.
+//                  integer atomic per distinct bucket (blocks own 16 x 16 pixel patches); the
+//                  binned pixel is written out for step 3;
+//   2. scan      : exclusive prefix sum of the bucket sizes; list of non-empty tiles in eight load
+//                  classes, heaviest first; the call's density picks the tile kernel;
+//   3. scatter   : writes the 20-byte point record of every (pixel, tile) pair into its bucket
+//                  slot (slot = bucket base + LDS-local rank);
+//   4. tile kernel, one of
+//        fuse_tiles_kernel   sparse frames, dense fp32 features, any tile shape: persistent
+//                  workgroups walk the tile list (ticket counter; the next tile's ticket, id,
+//                  offsets and first records are fetched one tile ahead).  The tile's old map
+//                  values are preloaded into LDS by LDS-DMA while pass 1 runs; frames are taken
+//                  in chunks: pass 1 accumulates W, S2 as 64-bit fixed-point LDS integer atomics
+//                  (ds_add_f32 is 29x slower than ds_add_u32 on gfx950), pass 2 turns them into
+//                  k_f = g_f / s_f per voxel, pass 3 adds w^2 k_f feat (compare-and-swap, float
+//                  atomic only on a lost race); the final pass writes s * D row by row;
+//        fuse_dense_kernel   real scenes (class ids / ones): everything accumulated as integers on
+//                  4 x 4 x 8 tiles, suffix form of the unrolled blend (see there);
+//        fuse_single_kernel / fuse_single_dense_kernel   single-group calls: one pass, integer sums.
 // No global float atomics are used (guide: ~1.3 TB/s, 17x slower when scattered); HBM sees each
-// touched voxel once per call, coalesced along z.
+// tile once per call, coalesced along z.
 //
 // Tuning / diagnostics, all off by default: MF_TILE="s0 s1 s2 threads [gc]" overrides the tile
-// shape, MF_STAMPS=1 prints the share of each phase of the tile kernel (dev builds of bench runs).
+// shape, MF_DENSE=0/1 pins the tile shape of multi-frame calls (MF_DENSE_FORCE also the kernel),
+// MF_DENSE_GC / MF_DENSE_NT its chunk and workgroup size, MF_BLOCKS caps the workgroups,
+// MF_STAMPS=1 prints the share of each phase of the tile kernel (dev builds of bench runs).
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -2144,6 +2151,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     // the all-integer tile kernel (class ids / ones, float4 rows, 4 x 4 x 8 tiles): launched next to the tile
     // kernel when the call was bucketed on its tiles; tile_list_kernel decides on the device which of the two runs
     static const int dense_nt = getenv("MF_DENSE_NT") ? atoi(getenv("MF_DENSE_NT")) : 512;
+    static const bool dense_forced = getenv("MF_DENSE_FORCE") != nullptr;      // dev / tests: the dense kernel whatever the density
     const int dgc = dense_chunk_frames(P.C, P.G);
     const size_t dlds = dense_lds_bytes(P.C, dgc);
     const bool use_dense = dense_tiles && sv == DENSE_SV && P.s2 == 3 && P.feat_kind != MF_FEAT_DENSE_F32 && P.vec4 &&
@@ -2178,7 +2186,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
                        P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
                        (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks,
-                       use_dense ? (1 << sv) | (getenv("MF_DENSE_FORCE") ? 1 << 20 : 0) : 0, 4 * blocks_dense);
+                       use_dense ? (1 << sv) | (dense_forced ? 1 << 20 : 0) : 0, 4 * blocks_dense);
     MF_LAUNCH_CHECK("tile_list_kernel");
     if (FRONT == 0 && P.G >= 2 && phase != 2) tile_hint_post(workspace, P.ticket + HINT_SLOT, st);
     prof_mark(2, st);
