@@ -41,12 +41,13 @@ def test_headline_launch_64_frames_vs_oracle(device):
     assert occupied > 900_000 * min(n, 8)
 
 
-def test_merged_4_frames_fullsize_vs_oracle(device):
-    """Merged batch semantics (all frames form one point set) at full size."""
+@pytest.mark.parametrize("n", [4, 8])
+def test_merged_frames_fullsize_vs_oracle(device, n):
+    """Merged batch semantics (all frames form one point set) at full size.  Four frames go
+    through the single-pass kernel, eight (more than 2^21 points) through the all-integer tile kernel."""
     from oracle import massref as orc
     from mass_amd.episodes import dist_a_frames
     from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
-    n = 4
     fr = dist_a_frames(n, seed0=100, height=H, width=W)
     lay = SemanticProjectionLayer(feature_size=C, **KW).to(device)
     lay.data.fill_(0.0625)
@@ -64,7 +65,7 @@ def test_merged_4_frames_fullsize_vs_oracle(device):
             pts[k].append(out[k])
     ix, iy, iz, rx, ry, rz, feats = (torch.cat(p) for p in pts)
     orc.update_feature_map(iy, ix, iz, ry, rx, rz, feats, ref.data, interpolation_weight=ref.interpolation_weight)
-    assert_map_close_device(lay.data, ref.data, what="4 frames merged")
+    assert_map_close_device(lay.data, ref.data, what=f"{n} frames merged")
 
 
 def test_config3_fullsize_three_maps_vs_oracle(device):
