@@ -2155,7 +2155,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     const int dgc = dense_chunk_frames(P.C, P.G);
     const size_t dlds = dense_lds_bytes(P.C, dgc);
     // (a merged batch of several frames is one group on 4 x 4 x 8 tiles anyway: the kernel is offered to it too)
-    const bool merged_batch = FRONT == 0 && P.G == 1 && P.n_frames >= 2;
+    static const int dense_min_frames = getenv("MF_DENSE_MIN_FRAMES") ? atoi(getenv("MF_DENSE_MIN_FRAMES")) : 2;   // dev
+    const bool merged_batch = FRONT == 0 && P.G == 1 && P.n_frames >= dense_min_frames;
     const bool use_dense = (dense_tiles || merged_batch) && sv == DENSE_SV && P.s2 == 3 && P.feat_kind != MF_FEAT_DENSE_F32 && P.vec4 &&
                        dlds <= (size_t)dev.lds_per_cu && (P.G + dgc - 1) / dgc <= DENSE_MAX_CHUNKS;
     const int dnt = dense_nt >= 1024 ? 1024 : 512;
