@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
         int o0, o1, o2;
         tile_origin(tile, o0, o1, o2);
         const int t_s = offs[0];
+        const bool big = offs[n_chunks] - t_s > NT * EB;     // more records than the registers hold
         int tile_n = -1;
         MF_STAMP(0)
         for (int c = 0; c < n_chunks; ++c) {
@@ -1171,20 +1172,29 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
                     atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
                 });
             };
-            // the tile's first NT * EB records are in registers (straight-line code: a loop header would make
-            // the compiler wait for every outstanding memory operation, the previous tile's stores included)
+            // A small tile (all its records fit the registers fetched a tile ahead) is taken from there, in
+            // straight-line code.  A big tile is dealt in SEGMENTS: thread t walks records [t * S, (t + 1) * S) of
+            // the chunk.  Neighbouring records come from neighbouring pixels and hit the same cells; dealt one
+            // per lane, a wave would pile its 64 lanes onto a handful of LDS words per atomic.  With segments the
+            // lanes of a wave are S records apart (other pixels, mostly other frames: other cells), and a lane's
+            // own consecutive records queue up behind each other instead of inside one instruction.
+            const int seg = (eb - ea + NT - 1) / NT;
+            const int my0 = min(eb, ea + tid * seg), my1 = min(eb, my0 + seg);
+            if (!big) {
 #pragma unroll
-            for (int j = 0; j < EB; ++j) {
-                const int e = t_s + tid + j * NT;
-                if (e >= ea && e < eb) p1_record(pre[j]);
-            }
-            for (int bb = max(ea, t_s + NT * EB); bb < eb; bb += NT * EB) {
-                uint4 r[EB];
+                for (int j = 0; j < EB; ++j) {
+                    const int e = t_s + tid + j * NT;
+                    if (e >= ea && e < eb) p1_record(pre[j]);
+                }
+            } else {
+                for (int e = my0; e < my1; e += EB) {
+                    uint4 r[EB];
 #pragma unroll
-                for (int j = 0; j < EB; ++j) r[j] = P.rec[min(bb + tid + j * NT, eb - 1)];
+                    for (int j = 0; j < EB; ++j) r[j] = P.rec[min(e + j, my1 - 1)];
 #pragma unroll
-                for (int j = 0; j < EB; ++j)
-                    if (bb + tid + j * NT < eb) p1_record(r[j]);
+                    for (int j = 0; j < EB; ++j)
+                        if (e + j < my1) p1_record(r[j]);
+                }
             }
             MF_STAMP(6)
             if (c == 0 && tid < 64) {                    // advance the look-ups
@@ -1279,23 +1289,26 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
                             if (m != 0ull) atomicAdd(&Di[KIND == 0 ? vi[cc] : vi[cc] * C + (int)x], m);
                         }
                 };
-#pragma unroll
-                for (int j = 0; j < EB; ++j) {
-                    const int e = t_s + tid + j * NT;
-                    if (e >= ea && e < eb && (KIND == 0 || prex[j] < (uint32_t)C)) p3_record(pre[j], prex[j]);
-                }
-                for (int bb = max(ea, t_s + NT * EB); bb < eb; bb += NT * EB) {
-                    uint4 r[EB];
-                    uint32_t x[EB];
+                if (!big) {
 #pragma unroll
                     for (int j = 0; j < EB; ++j) {
-                        const int e = min(bb + tid + j * NT, eb - 1);
-                        r[j] = P.rec[e];
-                        x[j] = KIND == 1 ? P.aux[e] : 0u;
+                        const int e = t_s + tid + j * NT;
+                        if (e >= ea && e < eb && (KIND == 0 || prex[j] < (uint32_t)C)) p3_record(pre[j], prex[j]);
                     }
+                } else {
+                    for (int e = my0; e < my1; e += EB) {
+                        uint4 r[EB];
+                        uint32_t x[EB];
 #pragma unroll
-                    for (int j = 0; j < EB; ++j)
-                        if (bb + tid + j * NT < eb && (KIND == 0 || x[j] < (uint32_t)C)) p3_record(r[j], x[j]);
+                        for (int j = 0; j < EB; ++j) {
+                            const int q = min(e + j, my1 - 1);
+                            r[j] = P.rec[q];
+                            x[j] = KIND == 1 ? P.aux[q] : 0u;
+                        }
+#pragma unroll
+                        for (int j = 0; j < EB; ++j)
+                            if (e + j < my1 && (KIND == 0 || x[j] < (uint32_t)C)) p3_record(r[j], x[j]);
+                    }
                 }
             }
             barrier_keep_vm();
