@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 //     (40 fraction bits; a positive term below one unit adds one unit, so that "non-zero" survives)
 //     and pass 3 is one dependent LDS read and integer atomics that return nothing;
 //   * the old map values never enter LDS: they are combined with prod a and D when the rows are stored
-//     (two workgroups per CU: one computes while the other moves its rows).
+//     (a real scene's tile holds tens of thousands of records: moving its 55 KB is noise).
 // Sums are exact and order independent: the result is run-to-run identical.
 // tile_list_kernel decides per call which tile kernel runs (ticket[MODE_SLOT]); the host picks the
 // tile shape from what the previous call on the same workspace counted (see tile_hint).
@@ -1038,7 +1038,7 @@ constexpr int DENSE_FX = 40;              // fraction bits of the deltas
 constexpr int DENSE_MAX_CHUNKS = 32;
 
 template <int KIND, int MAXT, bool STAMPS = false>
-__global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      // four waves per SIMD: two workgroups of 512 per CU
+__global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      // <= 128 VGPRs: two workgroups of 512 fit a CU when gc is small
 {
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -2246,8 +2246,12 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         T.fx_shift = 62 - bits; if (T.fx_shift > 50) T.fx_shift = 50;
     }
     T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);      // returns at once when the call went to the single-pass kernel
-    MF_LAUNCH_CHECK("fuse_tiles_kernel");
+    // with ones features every tile of a single-group call goes to the single-pass kernel (tile_list_kernel,
+    // min_mean = 0): nothing is listed for the tile kernel, whose launch is skipped
+    if (!(single && P.feat_kind == MF_FEAT_ONES)) {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);  // returns at once when the call went to another kernel
+        MF_LAUNCH_CHECK("fuse_tiles_kernel");
+    }
     if (use_dense) {
         void (*dk)(TileParams);
         if (dnt >= 1024) dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 1024, true> : fuse_dense_kernel<1, 1024, true>)
