@@ -1179,7 +1179,10 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
             // lanes of a wave are S records apart (other pixels, mostly other frames: other cells), and a lane's
             // own consecutive records queue up behind each other instead of inside one instruction.
             const int seg = (eb - ea + NT - 1) / NT;
-            const int my0 = min(eb, ea + tid * seg), my1 = min(eb, my0 + seg);
+            // segment of thread t: number 37 t mod NT (NT is a power of two), so that the lanes of a wave are
+            // neither in the same frame nor at the same place of neighbouring frames (the same surface)
+            const int my_seg = (tid * 37) & (NT - 1);
+            const int my0 = min(eb, ea + my_seg * seg), my1 = min(eb, my0 + seg);
             if (!big) {
 #pragma unroll
                 for (int j = 0; j < EB; ++j) {
