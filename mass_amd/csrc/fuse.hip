@@ -607,14 +607,19 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     unsigned long long *W64 = reinterpret_cast<unsigned long long *>(smem);   // [GC][TV]
     unsigned long long *S64 = W64 + (size_t)GC * TV;                           // [GC][TV]
     float *D = reinterpret_cast<float *>(S64 + (size_t)GC * TV);   // [TV][C] accumulated deltas (in units of s)
-    float *sc = D + (size_t)TV * C;                // [TV] s: decay not yet folded into D
-    float *osc = sc + TV;                          // [TV] prod a_f: factor of the old map value
-    int *offs2 = (int *)(osc + TV);                // [2][MAX_GROUPS + 1] bucket starts: this tile / next tile
-    int *cb = offs2 + 2 * (MAX_GROUPS + 1);        // [MAX_CHUNK + 1] entry offsets of the chunk's frames
-    int *misc = cb + MAX_CHUNK + 1;                // [0] first tile, [1] non-empty frame count, [2] tile after next, [3] second tile, [4..] class sizes
-    unsigned short *ne = (unsigned short *)(misc + 4 + TILE_CLASSES);   // [MAX_GROUPS] non-empty frames, ascending
-    unsigned char *touched = (unsigned char *)(ne + MAX_GROUPS);   // [TV]
+    // The float4 path (preloaded D, every row written) needs neither the factor of the old value nor the
+    // touched flags, and the per-group arrays are sized by the call's groups: with 64 frames at C = 54 that is
+    // the 4 KB that let a sixth frame into the chunk (tile_lds_fixed on the host mirrors this layout).
     const int G = P.G;
+    const bool lean = P.vec4 != 0;
+    const int OS = lean ? G + 1 : MAX_GROUPS + 1;  // stride of the two bucket-offset arrays
+    float *sc = D + (size_t)TV * C;                // [TV] s: decay not yet folded into D
+    float *osc = sc + TV;                          // [TV] prod a_f: factor of the old map value (not in the lean layout)
+    int *offs2 = (int *)(lean ? osc : osc + TV);   // [2][OS] bucket starts: this tile / next tile
+    int *cb = offs2 + 2 * OS;                      // [MAX_CHUNK + 1] entry offsets of the chunk's frames
+    int *misc = cb + MAX_CHUNK + 1;                // [0] first tile, [1] non-empty frame count, [2] tile after next, [3] second tile, [4..] class sizes
+    unsigned short *ne = (unsigned short *)(misc + 4 + TILE_CLASSES);   // [G | MAX_GROUPS] non-empty frames, ascending
+    unsigned char *touched = (unsigned char *)(ne + (lean ? ((G + 1) & ~1) : MAX_GROUPS));   // [TV] (not in the lean layout)
     const int m1 = (1 << P.s1) - 1, m2 = (1 << P.s2) - 1;
     const unsigned n_el = (unsigned)TV * (unsigned)C;
     const int fx_c = 182 - P.fx_shift;
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     while (tile >= 0) {
         int onext[OPT];
         if (tile_next >= 0) load_offs(tile_next, onext);      // in flight during the first chunk
-        const int *offs = offs2 + buf * (MAX_GROUPS + 1);
+        const int *offs = offs2 + buf * OS;
         const int t_a = offs[0];
         MF_STAMP(0)
         const int tz = tile % P.nt2, ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
         } else {
             for (unsigned i = tid; i < n_el; i += NT) D[i] = 0.0f;
         }
-        for (int v = tid; v < TV; v += NT) { sc[v] = 1.0f; osc[v] = 1.0f; touched[v] = 0; }
+        for (int v = tid; v < TV; v += NT) { sc[v] = 1.0f; if (!lean) { osc[v] = 1.0f; touched[v] = 0; } }
         barrier_keep_vm();
         MF_STAMP(1)
         const int n_ne = misc[1];
@@ -809,7 +814,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
             MF_STAMP(3)
             // pass 2: per voxel, frames in order: s *= a_f, k_f = g_f / s
             for (int v = tid; v < TV; v += NT) {
-                float s = sc[v], o = osc[v];
+                float s = sc[v], o = lean ? 1.0f : osc[v];
                 bool any = false;
                 for (int j = 0; j < nc; ++j) {
                     const unsigned long long wq = W64[j * TV + v];
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                         any = true;
                     }
                 }
-                if (any) { sc[v] = s; osc[v] = o; touched[v] = 1; }
+                if (any) { sc[v] = s; if (!lean) { osc[v] = o; touched[v] = 1; } }
             }
             __syncthreads();
             MF_STAMP(4)
@@ -930,12 +935,12 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                     });
                 }
             }
-            if (c0 == 0 && tile_next >= 0) store_offs(offs2 + (buf ^ 1) * (MAX_GROUPS + 1), onext);
+            if (c0 == 0 && tile_next >= 0) store_offs(offs2 + (buf ^ 1) * OS, onext);
             __syncthreads();
             MF_STAMP(5)
         }
 
-        if (tile_next >= 0) prefetch_entries(offs2 + (buf ^ 1) * (MAX_GROUPS + 1));   // lands during the final pass
+        if (tile_next >= 0) prefetch_entries(offs2 + (buf ^ 1) * OS);   // lands during the final pass
 
         // final pass: every touched voxel is read, combined and written once, with all of a
         // thread's loads in flight before the first store (one workgroup per CU: the loop is
@@ -1921,17 +1926,19 @@ static void choose_tile(const mf_grid *g, int n_groups, bool dense, int &s0, int
     s0 = rem - s1;
 }
 
-static size_t tile_lds_fixed(int C, int sv)
+static size_t tile_lds_fixed(int C, int sv, int G, bool lean)
 {
     const size_t TV = (size_t)1 << sv;
+    if (lean)       // float4 path: no factor of the old value, no touched flags, group arrays sized by G
+        return TV * C * 4 + TV * 4 + 2 * (size_t)(G + 1) * 4 + (MAX_CHUNK + 1) * 4 + (4 + TILE_CLASSES) * 4 + (size_t)((G + 1) & ~1) * 2 + 16;
     return TV * C * 4 + TV * 8 + 2 * (MAX_GROUPS + 1) * 4 + (MAX_CHUNK + 1) * 4 + (4 + TILE_CLASSES) * 4 + MAX_GROUPS * 2 + TV + 16;
 }
 
 // frames per chunk: what fits next to the tile's deltas, at most 64 KB of accumulators
-static int chunk_frames(int C, int sv, int G)
+static int chunk_frames(int C, int sv, int G, bool lean)
 {
     const size_t per_slot = ((size_t)1 << sv) * 16;
-    const size_t fixed = tile_lds_fixed(C, sv);
+    const size_t fixed = tile_lds_fixed(C, sv, G, lean);
     size_t avail = fixed + per_slot <= 160 * 1024 ? 160 * 1024 - fixed : per_slot;
     if (avail > 64 * 1024) avail = 64 * 1024;
     // small tiles: four workgroups per CU (their memory and compute phases overlap) matter more than long chunks
@@ -1944,9 +1951,9 @@ static int chunk_frames(int C, int sv, int G)
     return gc;
 }
 
-static size_t tile_lds_bytes(int C, int sv, int gc)
+static size_t tile_lds_bytes(int C, int sv, int gc, int G, bool lean)
 {
-    return tile_lds_fixed(C, sv) + (size_t)gc * ((size_t)1 << sv) * 16;
+    return tile_lds_fixed(C, sv, G, lean) + (size_t)gc * ((size_t)1 << sv) * 16;
 }
 
 struct Layout {
@@ -2141,13 +2148,13 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
                                        : dim3((unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS));
     // ---- configuration of the tile kernel (needed by both halves: its grid size seeds the ticket counter) ----
     const int sv = P.s0 + P.s1 + P.s2;
-    P.gc = chunk_frames(P.C, sv, P.G);
+    P.vec4 = ((uintptr_t)P.map % 16 == 0) && ((P.C << P.s2) % 4 == 0) && (P.size2 % (1 << P.s2) == 0) &&
+             ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34));
+    P.gc = chunk_frames(P.C, sv, P.G, P.vec4 != 0);
     // a commit on its own is meant to run beside the staging kernels of the next batch: one frame less per
     // chunk leaves 8 KB of LDS per CU for their workgroups (with all of it taken they cannot start at all)
     if (phase != 3 && P.gc > 2) P.gc -= 1;
-    P.vec4 = ((uintptr_t)P.map % 16 == 0) && ((P.C << P.s2) % 4 == 0) && (P.size2 % (1 << P.s2) == 0) &&
-             ((size_t)P.size0 * P.size1 * P.size2 * P.C < ((size_t)1 << 34));
-    const size_t lds = tile_lds_bytes(P.C, sv, P.gc);
+    const size_t lds = tile_lds_bytes(P.C, sv, P.gc, P.G, P.vec4 != 0);
     const DeviceInfo &dev = device_info();
     if (lds > (size_t)dev.lds_per_cu)
         return fail(MF_ERR_INVALID, "tile needs %zu bytes of LDS, device has %d", lds, dev.lds_per_cu);
