@@ -27,12 +27,15 @@ rm -rf $outb && mkdir -p $outb
 rocprofv3 --kernel-trace --stats --output-format csv -d $outb/kt -o runc -- $BENCHB > $outb/bench_under_kt.json 2> $outb/kt.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $outb/fetch -o runc -- python3 bench.py --workload room --steps 6 --warmup 3 --no-extras --no-cpu-baseline > /dev/null 2> $outb/fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $outb/write -o runc -- python3 bench.py --workload room --steps 6 --warmup 3 --no-extras --no-cpu-baseline > /dev/null 2> $outb/write.err || exit 1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $outb/sq -o runc -- python3 bench.py --workload room --steps 6 --warmup 3 --no-extras --no-cpu-baseline --no-pipeline > /dev/null 2> $outb/sq.err || exit 1
+python3 tools/pmc_summary.py $outb/sq mf:: > $outb/sq_summary.txt
 echo "room done"
 # summarise here (the raw traces are too bulky to travel back), keep the summaries only
 mkdir -p gpurun_out/prof_summary
 MF_PROFILE_OUT=gpurun_out/prof_summary python3 tools/summarize_profiles.py ${1:-r02} distA_sequential_b64 > gpurun_out/prof_summary/summary.log 2>&1 || { tail -5 gpurun_out/prof_summary/summary.log; exit 1; }
 MF_PROFILE_SRC=$outb MF_PROFILE_KERNEL=mf::fuse_dense_kernel MF_PROFILE_OUT=gpurun_out/prof_summary python3 tools/summarize_profiles.py ${1:-r02}_room room_sequential_b64 > gpurun_out/prof_summary/summary_room.log 2>&1 || { tail -5 gpurun_out/prof_summary/summary_room.log; exit 1; }
 cp $outb/bench_under_kt.json gpurun_out/prof_summary/${1:-r02}_room_bench_under_rocprof.json
+cp $outb/sq_summary.txt gpurun_out/prof_summary/${1:-r02}_room_sq_counters.txt
 rm -rf $outb
 cp $out/bench_under_kt.json gpurun_out/prof_summary/${1:-r02}_bench_under_rocprof.json
 cp $out/single_frame_updates.jsonl gpurun_out/prof_summary/${1:-r02}_single_frame_updates.jsonl
