@@ -105,3 +105,32 @@ def test_dense_kernel_three_chunks_vs_oracle(device, iw):
         assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"iw {iw} batch {half}")
     wptr, _ = lay._workspace.get(1, lay.data.device)
     assert _lib.lib.mf_fuse_tile_hint(wptr) == 1
+
+
+def test_pipelined_room_batches_switch_tile_shape_midstream(device):
+    """FusePipeline (stage on a side stream, commit in order, two workspaces) over a room trajectory: the density
+    words of the first batches arrive while later ones are being staged, so the tile shape changes from 8x8x8 to
+    4x4x8 somewhere in the stream, per workspace; a commit must use what its own staging used.  Checked against
+    the oracle loop."""
+    from mass_amd import _lib
+    from mass_amd.episodes import room_trajectory
+    from mass_amd.utils.projection import FusePipeline
+    nb, per = 6, 8
+    tr = room_trajectory(nb * per, H, W, seed=11, num_classes=C)
+    lay, ref = _layers(device, "label")
+    pipe = FusePipeline(device)
+    for b in range(nb):
+        sl = slice(b * per, (b + 1) * per)
+        poses = lay._poses(tr["position"][sl], tr["yaw"][sl], tr["elevation"][sl])
+        pipe.submit(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, tr["depth"][sl].to(device).reshape(per, H, W),
+                    tr["semantic"][sl].to(device), lay.data, interpolation_weight=lay.interpolation_weight, sequential=True)
+        if b == 2:
+            torch.cuda.synchronize()                     # by now both workspaces have measured a dense batch
+    pipe.flush()
+    torch.cuda.synchronize()
+    hints = [_lib.lib.mf_fuse_tile_hint(ws.get(1, lay.data.device)[0]) for ws in pipe.ws]
+    assert hints == [1, 1]
+    for t in range(nb * per):
+        ref.update(dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t], depth=tr["depth"][t],
+                        features=torch.nn.functional.one_hot(tr["semantic"][t].long(), C).float()))
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="pipelined room batches")
