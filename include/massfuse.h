@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 3
+#define MF_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define MF_API __attribute__((visibility("default")))
@@ -61,6 +61,9 @@ extern "C" {
 /* Voxel map + bin edges.  Replaces the buffers of BaseProjectionLayer
  * (base_projection_layer.py:153-181). */
 typedef struct mf_grid {
+    uint32_t struct_size;               /* = sizeof(mf_grid), set by the caller: every entry point that takes the
+                                           struct refuses a different value (a binding written against another ABI
+                                           version fails with MF_ERR_INVALID instead of reading past its struct) */
     int32_t size0, size1, size2;        /* map_height, map_width, map_depth (each <= 1024)            */
     int32_t channels;                   /* feature_size C                                              */
     const float *bins_x;                /* device, n_edges_x floats (world axis 0)                     */
@@ -73,6 +76,7 @@ typedef struct mf_grid {
 /* A batch of posed RGB-D(+feature) frames.  Replaces the observation dict of
  * BaseProjectionLayer.update (base_projection_layer.py:309-325). */
 typedef struct mf_frames {
+    uint32_t struct_size;               /* = sizeof(mf_frames), checked like mf_grid.struct_size            */
     int32_t n_frames;
     int32_t height, width;              /* camera resolution of `depth` and `cam_rays`                 */
     const float *cam_rays;              /* device [height*width*3]: the layer's `rays` buffer
@@ -87,16 +91,21 @@ typedef struct mf_frames {
                                            (repeat_interleave upsampling, base_projection_layer.py:322-325) */
     float min_depth, max_depth;         /* bin_rays min_ray_depth / max_ray_depth (0, 10)              */
     int32_t *label_status;              /* optional (may be NULL), MF_FEAT_LABEL_* only: a device-visible
-                                           int32 (pinned host memory works) that is set to 1 when a valid
-                                           pixel carries a class id outside [0, channels); the call then
-                                           leaves the map untouched, like the reference, whose one_hot
-                                           raises before anything is written
-                                           (semantic_projection_layer.py:203-209).  With NULL such ids
-                                           count as an all-zero feature row.                             */
+                                           int32 (pinned host memory works) that is set to 1 when ANY pixel of
+                                           the batch (valid depth or not: the reference's one_hot looks at the
+                                           whole image) carries a class id outside [0, channels); the call then
+                                           leaves the map untouched, like the reference, whose one_hot raises
+                                           before anything is written (semantic_projection_layer.py:203-209).
+                                           With NULL such ids count as an all-zero feature row.              */
 } mf_frames;
 
 MF_API int mf_version(void);
 MF_API const char *mf_last_error(void);
+
+/* sizeof(mf_grid) / sizeof(mf_frames) as this library was compiled: a binding compares them with its own
+ * mirror of the structs when it loads the library (mass_amd/_lib.py does, and refuses to import on a
+ * mismatch).  Either pointer may be NULL. */
+MF_API int mf_struct_sizes(size_t *grid_bytes, size_t *frames_bytes);
 
 /* ---- parity entry points (one per reference function) --------------------- */
 

@@ -20,21 +20,31 @@ FEAT_ONES, FEAT_LABEL_U8, FEAT_LABEL_I32, FEAT_LABEL_I64, FEAT_DENSE_F32 = 0, 1,
 MODE_SEQUENTIAL, MODE_MERGED = 0, 1
 METRIC_L2, METRIC_L2_GEMM, METRIC_COSINE = 0, 1, 2
 MAX_FRAMES_PER_CALL = 256
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_float, ctypes.c_size_t)
 
 
-class MfGrid(ctypes.Structure):
-    _fields_ = [("size0", c_int32), ("size1", c_int32), ("size2", c_int32), ("channels", c_int32),
+class _SizedStruct(ctypes.Structure):
+    """Mirror of a C struct whose first member is `uint32_t struct_size` (= sizeof, the ABI handshake
+    of include/massfuse.h): filled in on construction."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if not args and "struct_size" not in kw:
+            self.struct_size = ctypes.sizeof(self)
+
+
+class MfGrid(_SizedStruct):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("size0", c_int32), ("size1", c_int32), ("size2", c_int32), ("channels", c_int32),
                 ("bins_x", c_void_p), ("bins_y", c_void_p), ("bins_z", c_void_p),
                 ("n_edges_x", c_int32), ("n_edges_y", c_int32), ("n_edges_z", c_int32),
                 ("map", c_void_p)]
 
 
-class MfFrames(ctypes.Structure):
-    _fields_ = [("n_frames", c_int32), ("height", c_int32), ("width", c_int32),
+class MfFrames(_SizedStruct):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("n_frames", c_int32), ("height", c_int32), ("width", c_int32),
                 ("cam_rays", c_void_p), ("poses", c_void_p), ("depth", c_void_p), ("feat", c_void_p),
                 ("feat_kind", c_int32), ("feat_height", c_int32), ("feat_width", c_int32),
                 ("min_depth", c_float), ("max_depth", c_float), ("label_status", c_void_p)]
@@ -44,6 +54,7 @@ class MfFrames(ctypes.Structure):
 SIGNATURES = {
     "mf_version": (ctypes.c_int, []),
     "mf_last_error": (ctypes.c_char_p, []),
+    "mf_struct_sizes": (ctypes.c_int, [ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "mf_transform_rays": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "mf_bin_rays": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                                    c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64,
@@ -97,6 +108,12 @@ def _load():
         fn.restype, fn.argtypes = res, args
     if lib.mf_version() != ABI_VERSION:
         raise ImportError(f"libmassfuse.so ABI {lib.mf_version()} != expected {ABI_VERSION}; rebuild it")
+    gs, fs = c_size_t(0), c_size_t(0)
+    lib.mf_struct_sizes(ctypes.byref(gs), ctypes.byref(fs))
+    if (gs.value, fs.value) != (ctypes.sizeof(MfGrid), ctypes.sizeof(MfFrames)):
+        raise ImportError(f"struct layout mismatch: libmassfuse.so has sizeof(mf_grid) = {gs.value}, sizeof(mf_frames) = "
+                          f"{fs.value}; mass_amd/_lib.py mirrors {ctypes.sizeof(MfGrid)} and {ctypes.sizeof(MfFrames)} "
+                          "(include/massfuse.h and _lib.py are out of step)")
     return lib
 
 

@@ -35,4 +35,11 @@ int mf_version(void) { return MF_ABI_VERSION; }
 
 const char *mf_last_error(void) { return mf::error_buffer(); }
 
+int mf_struct_sizes(size_t *grid_bytes, size_t *frames_bytes)
+{
+    if (grid_bytes) *grid_bytes = sizeof(mf_grid);
+    if (frames_bytes) *frames_bytes = sizeof(mf_frames);
+    return MF_OK;
+}
+
 }

@@ -2026,6 +2026,9 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
 static int check_grid(const mf_grid *g, bool need_bins)
 {
     if (!g) return fail(MF_ERR_INVALID, "grid is NULL");
+    if (g->struct_size != sizeof(mf_grid))
+        return fail(MF_ERR_INVALID, "mf_grid.struct_size is %u, this library (ABI %d) expects %zu: the binding was "
+                    "written against another version of include/massfuse.h", g->struct_size, MF_ABI_VERSION, sizeof(mf_grid));
     if (g->size0 < 1 || g->size1 < 1 || g->size2 < 1 || g->size0 > 1024 || g->size1 > 1024 || g->size2 > 1024)
         return fail(MF_ERR_INVALID, "map dims must be in [1, 1024], got %d x %d x %d", g->size0, g->size1, g->size2);
     if (g->channels < 1 || g->channels > 8192)
@@ -2043,6 +2046,9 @@ static int check_grid(const mf_grid *g, bool need_bins)
 static int check_frames(const mf_frames *f, int C)
 {
     if (!f) return fail(MF_ERR_INVALID, "frames is NULL");
+    if (f->struct_size != sizeof(mf_frames))
+        return fail(MF_ERR_INVALID, "mf_frames.struct_size is %u, this library (ABI %d) expects %zu: the binding was "
+                    "written against another version of include/massfuse.h", f->struct_size, MF_ABI_VERSION, sizeof(mf_frames));
     if (f->n_frames < 1 || f->height < 1 || f->width < 1)
         return fail(MF_ERR_INVALID, "n_frames/height/width must be positive");
     if (!f->cam_rays || !f->poses || !f->depth) return fail(MF_ERR_INVALID, "cam_rays/poses/depth pointer is NULL");
@@ -2485,8 +2491,9 @@ int mf_unproject_bin(const mf_grid *grid, const mf_frames *frames, int64_t *ind_
 {
     int rc = check_grid(grid, true);
     if (rc != MF_OK) return rc;
-    if (!frames || !frames->cam_rays || !frames->poses || !frames->depth || frames->n_frames < 1)
-        return fail(MF_ERR_INVALID, "frames incomplete");
+    if (!frames || frames->struct_size != sizeof(mf_frames) || !frames->cam_rays || !frames->poses || !frames->depth ||
+        frames->n_frames < 1)
+        return fail(MF_ERR_INVALID, "frames incomplete (or mf_frames.struct_size != %zu)", sizeof(mf_frames));
     FuseParams P = {};
     fill_grid(P, grid);
     mf_frames f = *frames;

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as functional
 
 from mass_amd import _lib
-from mass_amd._lib import lib, check, ptr, current_stream
+from mass_amd._lib import lib, check, ptr, current_stream, MAX_FRAMES_PER_CALL
 from mass_amd.nn.base_projection_layer import BaseProjectionLayer
 from mass_amd.utils.reductions import amax_z
 
@@ -98,23 +98,31 @@ class SemanticProjectionLayer(BaseProjectionLayer):
     def _update(self, observation, sequential, validate):
         if validate == "defer":
             self.check_labels(synchronize=False)         # whatever an earlier update has reported by now
+        labels = self._labels(observation["semantic"])
+        if validate is True and sequential and labels.dim() == 3 and labels.shape[0] > MAX_FRAMES_PER_CALL:
+            # such a batch is issued in several library calls: look at all of its ids first, so that a raise
+            # leaves the map untouched like a single call does
+            if bool(((labels < 0) | (labels >= self.feature_size)).any()):
+                raise RuntimeError(self._CLASS_ERROR)
         self._splat(observation["position"], observation["yaw"], observation["elevation"],
-                    observation["depth"], self._labels(observation["semantic"]), sequential=sequential,
+                    observation["depth"], labels, sequential=sequential,
                     label_status=self._status() if validate else None)
         if validate is True:
             self.check_labels(synchronize=True)
         return self
 
-    def update(self, observation: Dict[str, torch.Tensor], validate="defer"):
+    def update(self, observation: Dict[str, torch.Tensor], validate=True):
         """semantic_projection_layer.py:165-216.  Class ids outside [0, feature_size) raise like the
         reference's one_hot (:203-209) and leave the map untouched: the kernels detect them and call
-        the update off.  validate="defer" (default) does not wait for the GPU: the RuntimeError
-        surfaces at the next update() / find() / reset() / check_labels() of this layer, the way
-        device-side errors usually do; validate=True waits for the update and raises from this very
-        call; False skips the check (such ids then count as an all-zero feature row)."""
+        the update off.  validate=True (default, the reference's behaviour) waits for this update's
+        kernels (one stream synchronisation) and raises from this very call; validate="defer" does not
+        wait: the RuntimeError surfaces at the next update() / find() / reset() / check_labels() of this
+        layer, the way device-side errors usually do (callers that read .data directly call
+        check_labels() first); False skips the check (such ids then count as an all-zero feature row).
+        INTEGRATION.md has the table."""
         return self._update(observation, True, validate)
 
-    def update_batch(self, observation: Dict[str, torch.Tensor], sequential: bool = True, validate="defer"):
+    def update_batch(self, observation: Dict[str, torch.Tensor], sequential: bool = True, validate=True):
         return self._update(observation, sequential, validate)
 
     # ------------------------------------------------------------------ find

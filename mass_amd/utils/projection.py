@@ -250,13 +250,15 @@ def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, featur
     layer.update() calls, False the functional API's merged batch.
 
     label_status: optional pinned-host (or device) int32 tensor; the kernels set it to 1 and leave
-    the map untouched when a valid pixel carries a class id outside [0, C) (mf_frames.label_status)."""
+    the map untouched when a pixel carries a class id outside [0, C) (mf_frames.label_status)."""
     g, fr, fm, B, H, W, (depth, poses, feat, *_keep) = _frames_call(
         bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map, min_ray_depth, max_ray_depth, label_status)
     ws = workspace or _default_workspace
     stream = current_stream(fm.device)
     step = _lib.MAX_FRAMES_PER_CALL if sequential else B
     for b0 in range(0, B, step):
+        if b0 > 0 and label_status is not None and int(label_status.reshape(-1)[0]) != 0:
+            break            # a class id out of range has been reported: no further part of the batch is applied
         nb = min(step, B - b0)
         fr.n_frames = nb
         fr.poses = poses[b0:].data_ptr()

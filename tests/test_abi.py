@@ -32,6 +32,63 @@ def test_version_matches_header():
     assert int(re.search(r"#define MF_ABI_VERSION (\d+)", text).group(1)) == _lib.lib.mf_version()
 
 
+def header_struct_fields(name):
+    """Member names of `typedef struct <name> {...}` in include/massfuse.h, in order."""
+    text = open(os.path.join(ROOT, "include", "massfuse.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.findall(r"\**(\w+)\s*$", part.strip())[0])
+    return fields
+
+
+def integration_stub_fields(cls):
+    """The `_fields_` list of class `cls` in INTEGRATION.md's ctypes stub (names and ctypes type names)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    body = re.search(r"class %s\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\n" % cls, text, re.S).group(1)
+    return re.findall(r'\("(\w+)",\s*ctypes\.(\w+)\)', body)
+
+
+def test_struct_layout_handshake():
+    """ABI 4: mf_struct_sizes equals the ctypes mirrors (checked at import too), the header's members equal the
+    mirrors' field for field, and so does the stub INTEGRATION.md shows a maintainer (it had
+    fallen a field behind and nothing noticed)."""
+    gs, fs = ctypes.c_size_t(), ctypes.c_size_t()
+    assert _lib.lib.mf_struct_sizes(ctypes.byref(gs), ctypes.byref(fs)) == _lib.MF_OK
+    assert (gs.value, fs.value) == (ctypes.sizeof(_lib.MfGrid), ctypes.sizeof(_lib.MfFrames))
+    for cname, cls, doc in (("mf_grid", _lib.MfGrid, "MfGrid"), ("mf_frames", _lib.MfFrames, "MfFrames")):
+        mirror = list(cls._fields_)
+        assert header_struct_fields(cname) == [n for n, _ in mirror], cname
+        stub = [(n, getattr(ctypes, t)) for n, t in integration_stub_fields(doc)]
+        assert stub == mirror, f"INTEGRATION.md stub of {doc} is out of step with mass_amd/_lib.py"
+    assert "lib.mf_version() == %d" % _lib.ABI_VERSION in open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+
+def test_structs_of_another_size_are_refused():
+    g = _lib.MfGrid()
+    g.size0 = g.size1 = g.size2 = 8
+    g.channels = 3
+    g.map = 256
+    assert _lib.lib.mf_fuse_workspace_bytes(g, 100, 1) > 0
+    g.struct_size -= 8                                   # a binding written against a shorter struct
+    assert _lib.lib.mf_fuse_workspace_bytes(g, 100, 1) == 0
+    assert b"struct_size" in _lib.lib.mf_last_error()
+    g.struct_size += 8
+    f = _lib.MfFrames()
+    f.struct_size = 72                                   # ABI 2's mf_frames (no label_status)
+    f.n_frames, f.height, f.width = 1, 4, 4
+    f.cam_rays = f.poses = f.depth = 256
+    g.bins_x = g.bins_y = g.bins_z = 256
+    g.n_edges_x = g.n_edges_y = g.n_edges_z = 9
+    assert _lib.lib.mf_fuse_frames(g, f, 0.5, 0, None, 0, None) == _lib.MF_ERR_INVALID
+    assert b"mf_frames.struct_size" in _lib.lib.mf_last_error()
+
+
 def test_argument_validation_needs_no_gpu():
     g = _lib.MfGrid()
     assert _lib.lib.mf_fuse_workspace_bytes(g, 10, 1) == 0

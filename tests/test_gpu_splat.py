@@ -217,8 +217,8 @@ def test_resnet_layer_splat_at_quarter_resolution(device):
 
 def test_out_of_range_class_ids_raise_and_leave_the_map_untouched(device):
     """The reference's one_hot raises on a class id outside [0, C) before anything is written
-    (semantic_projection_layer.py:203-209): so does update() by default, with the map untouched;
-    validate="defer" reports at the next call; validate=False counts such ids as zero rows."""
+    (semantic_projection_layer.py:203-209): so does update() by default (validate=True), with the map
+    untouched; validate="defer" reports at the next call; validate=False counts such ids as zero rows."""
     from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
     from oracle import massref as orc
     H, W, C, M = SMALL["H"], SMALL["W"], 5, SMALL["MAP"]
@@ -235,18 +235,18 @@ def test_out_of_range_class_ids_raise_and_leave_the_map_untouched(device):
         bad = good.clone().to(dtype)
         bad[H // 2, W // 2, 0] = bad_value
         with pytest.raises(RuntimeError, match="Class values"):
-            lay.update(dict(obs, semantic=bad), validate=True)
+            lay.update(dict(obs, semantic=bad))                    # default: raises from the offending call
         assert torch.equal(lay.data, before)                      # the update was called off as a whole
     lay.update(dict(obs, semantic=good))                           # and the layer keeps working
     assert not torch.equal(lay.data, before)
     # deferred: reported by the next call (or check_labels), map untouched by the bad frame
     mid = lay.data.clone()
     bad = good.clone(); bad[0, 0, 0] = C
-    lay.update(dict(obs, semantic=bad))                            # default: validate="defer"
+    lay.update(dict(obs, semantic=bad), validate="defer")
     with pytest.raises(RuntimeError, match="Class values"):
         lay.check_labels()
     assert torch.equal(lay.data, mid)
-    lay.update(dict(obs, semantic=bad))
+    lay.update(dict(obs, semantic=bad), validate="defer")
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="Class values"):        # ... or the next call into the layer
         lay.update(dict(obs, semantic=good))
