@@ -148,13 +148,12 @@ MF_API size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int
  * semantic_projection_layer.py:203-214 / occupancy_projection_layer.py:159-161).
  * Updates grid->map in place.  n_frames <= 256 per call.
  * The workspace needs no initialisation and holds nothing between calls.
- * A call of several sequential frames picks its map-tile shape (8x8x8, or 4x4x8 with
- * the all-integer tile kernel for real scenes) from the point density the PREVIOUS call
- * with the same workspace pointer measured: two words are copied to pinned host memory
- * behind the call and read, without waiting, at the start of the next one (per
- * workspace the library keeps one event and 8 pinned bytes; MF_DENSE=0/1 in the
- * environment pins the choice).  The result does not depend on the choice beyond the
- * stated tolerance. */
+ * Sequential frames of class ids / ones are bucketed on 4x4x8 map tiles and fused by one of two
+ * all-integer tile kernels, picked on the device from the call's point density (fuse_cells_kernel
+ * for unrelated / sparse frames, fuse_dense_kernel for real scenes); everything else (dense fp32
+ * features, blend weights outside [0, 1], odd map shapes) takes fuse_tiles_kernel.  The choice is a
+ * function of the call's arguments and data only: the library keeps no state between calls, and the
+ * integer kernels give run-to-run identical bits. */
 MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
                    int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -228,11 +227,12 @@ MF_API int mf_roi_moments(const float *map, int32_t size0, int32_t size1, int32_
 MF_API int mf_profile_enable(int32_t on);
 MF_API int mf_profile_read(int32_t call, float *ms /* [5] host */);
 
-/* What the next multi-frame call with this workspace pointer will be bucketed on, as far as
- * the calls before it are known to have finished (see mf_fuse_frames): 1 = 4x4x8 tiles and
- * the all-integer tile kernel (the last finished call found a real scene), 0 = 8x8x8 tiles.
- * Never waits.  Used by the tests to prove which path ran. */
-MF_API int mf_fuse_tile_hint(const void *workspace);
+/* Which tile kernel took the most recent multi-frame call of class-id / ones frames issued with
+ * this workspace (same grid, n_points and n_groups as that call): 0 fuse_tiles_kernel,
+ * 2 fuse_dense_kernel, 3 fuse_cells_kernel; < 0 on error.  Reads one word of the workspace back and
+ * WAITS for `stream`.  Used by the tests to prove which path ran. */
+MF_API int mf_fuse_last_mode(const mf_grid *grid, int64_t n_points, int32_t n_groups, const void *workspace,
+                             void *stream);
 
 /* ---- matching (experimentation.py:261-265, 277-280, 284-287) --------------- */
 

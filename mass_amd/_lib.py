@@ -21,6 +21,7 @@ MODE_SEQUENTIAL, MODE_MERGED = 0, 1
 METRIC_L2, METRIC_L2_GEMM, METRIC_COSINE = 0, 1, 2
 MAX_FRAMES_PER_CALL = 256
 ABI_VERSION = 4
+MODE_TILES, MODE_DENSE, MODE_CELLS = 0, 2, 3          # mf_fuse_last_mode
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_float, ctypes.c_size_t)
@@ -81,7 +82,7 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "mf_profile_enable": (ctypes.c_int, [c_int32]),
     "mf_profile_read": (ctypes.c_int, [c_int32, c_void_p]),
-    "mf_fuse_tile_hint": (ctypes.c_int, [c_void_p]),
+    "mf_fuse_last_mode": (ctypes.c_int, [ctypes.POINTER(MfGrid), c_int64, c_int32, c_void_p, c_void_p]),
     "mf_pairwise_distance": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,
                                             c_int32, c_void_p]),
     "mf_linear_sum_assignment": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

@@ -97,8 +97,11 @@ struct TileParams {
     int nt1, nt2, n_tiles;
     unsigned magicC;
     int gc, vec4, fx_shift;
+    int cells_cap;             // fuse_cells_kernel: (voxel, frame) cells that fit its LDS
+    int mode_force;            // >= 0: the tile kernel with this mode number runs whatever tile_list_kernel chose (commit-time override)
     const int *cursor;
     int *ticket;
+    int *ctr;                  // this kernel's work counter (one word of `ticket` per tile kernel)
     const int *active;
     const uint4 *rec;
     const uint32_t *aux;
@@ -397,8 +400,11 @@ __device__ __forceinline__ int tile_class(int n)
 // every non-empty tile, one with more than split_min records cut into `nparts` record ranges.
 constexpr int SPLIT_ITEMS = ABORT_SLOT + 1, SPLIT_TILES = ABORT_SLOT + 2, SPLIT_NONEMPTY = ABORT_SLOT + 3;
 constexpr int FEAT_ABSMAX = ABORT_SLOT + 4;     // bits of max |feature| of the call (dense single-pass path)
-constexpr int MODE_SLOT = ABORT_SLOT + 5;       // which tile kernel takes the call: 0 fuse_tiles_kernel, 2 fuse_dense_kernel
-constexpr int HINT_SLOT = ABORT_SLOT + 6;       // [2] records listed, non-empty buckets x tile voxels / 2: read back by the host (tile_hint)
+constexpr int MODE_SLOT = ABORT_SLOT + 5;       // which tile kernel takes the call: 0 fuse_tiles_kernel, 2 fuse_dense_kernel, 3 fuse_cells_kernel
+constexpr int HINT_SLOT = ABORT_SLOT + 6;       // [2] records listed, non-empty buckets x tile voxels / 2 (diagnostics)
+constexpr int TICKET_DENSE = ABORT_SLOT + 8;    // work counter of fuse_dense_kernel (ticket[0] is fuse_tiles_kernel's)
+constexpr int TICKET_CELLS = ABORT_SLOT + 9;    // work counter of fuse_cells_kernel
+constexpr int MODE_TILES = 0, MODE_DENSE = 2, MODE_CELLS = 3;
 constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
 constexpr int SPLIT_PARTS_MAX = 64;
@@ -408,19 +414,24 @@ __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ 
                                                         int n_tiles, int G, int *ticket, int *active,
                                                         int split_min, int split_part, int split_slots, int *items,
                                                         int min_mean, int first_ticket, int dense_tv,
-                                                        int first_ticket_dense)
+                                                        int first_ticket_dense, int first_ticket_cells)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
         // Density of the call: records per non-empty (tile, frame) bucket and tile voxel.  Half a record per
         // voxel and frame or more is a real scene (a batch of unrelated frames has 0.03): the all-integer
         // tile kernel takes it when the call was bucketed on its tiles (dense_tv = their voxel count, else 0).
-        const long long total = cursor[n_tiles * G], half = (long long)ticket[SPLIT_NONEMPTY] * (dense_tv > 0 ? (dense_tv & 0xfffff) : 512) / 2;
-        const bool dense = dense_tv > 0 && (total >= half || (dense_tv & (1 << 20)));     // bit 20: forced (dev)
-        ticket[MODE_SLOT] = dense ? 2 : 0;
+        const long long total = cursor[n_tiles * G], half = (long long)ticket[SPLIT_NONEMPTY] * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
+        // bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is, bits 22 / 23: forced (dev / tests)
+        const bool dense_ok = dense_tv & (1 << 20), cells_ok = dense_tv & (1 << 21);
+        const bool dense = dense_ok && !(dense_tv & (1 << 23)) && (total >= half || (dense_tv & (1 << 22)));
+        ticket[MODE_SLOT] = dense ? MODE_DENSE : cells_ok ? MODE_CELLS : MODE_TILES;
         ticket[HINT_SLOT] = (int)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
         ticket[HINT_SLOT + 1] = (int)(half > 0x7fffffffLL ? 0x7fffffffLL : half);
-        ticket[0] = dense ? first_ticket_dense : first_ticket;   // the tile kernels deal their first items statically (see there)
+        // every tile kernel deals its first items statically (see there) and has a work counter of its own
+        ticket[0] = first_ticket;
+        ticket[TICKET_DENSE] = first_ticket_dense;
+        ticket[TICKET_CELLS] = first_ticket_cells;
     }
     int n = 0;
     if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     // wait (the old-map preload): nothing else is outstanding there, so reading the results of the
     // loads issued one tile earlier costs no wait of its own (vmcnt retires in order: waiting for an
     // old load at any other point would also wait for every younger load and store of the wave).
-    if (P.ticket[MODE_SLOT] != 0) return;                                        // fuse_dense_kernel takes the call (uniform)
+    if ((P.mode_force >= 0 ? P.mode_force : P.ticket[MODE_SLOT]) != MODE_TILES) return;   // another tile kernel takes the call (uniform)
     {
         int listed = 0;
 #pragma unroll
@@ -807,7 +818,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
                 if (tid == 0) {                                        // advance the ticket pipeline (see above)
                     misc[2] = act_pend;
                     act_pend = resolve(idx_pend);
-                    idx_pend = atomicAdd(P.ticket, 1);
+                    idx_pend = atomicAdd(P.ctr, 1);
                 }
             }
             barrier_keep_vm();
@@ -1067,7 +1078,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
     const float di_inv = __uint_as_float((unsigned)(127 - DENSE_FX) << 23);    // 2^-DENSE_FX
 
-    if (P.ticket[MODE_SLOT] != 2) return;                                      // another tile kernel takes the call (uniform)
+    if ((P.mode_force >= 0 ? P.mode_force : P.ticket[MODE_SLOT]) != MODE_DENSE) return;   // another tile kernel takes the call (uniform)
     {
         int listed = 0;
 #pragma unroll
@@ -1113,7 +1124,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
         rng_tile = resolve(b + 2 * nb);
         rng_off = chunk_off(rng_tile);
         act_pend = resolve(b + 3 * nb);
-        idx_pend = tid == 0 ? atomicAdd(P.ticket, 1) : 0;
+        idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
         idx_pend = __shfl(idx_pend, 0, 64);
     }
     __syncthreads();
@@ -1212,7 +1223,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
                 rng_tile = act_pend;
                 rng_off = chunk_off(rng_tile);
                 act_pend = resolve(idx_pend);
-                idx_pend = tid == 0 ? atomicAdd(P.ticket, 1) : 0;
+                idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
                 idx_pend = __shfl(idx_pend, 0, 64);
             }
             barrier_keep_vm();
@@ -1356,6 +1367,354 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
         tile = tile_n;
         if (tid <= n_chunks) offs[tid] = offs_n[tid];       // read by everyone after the next barrier ...
         barrier_keep_vm();                                   // ... which is this one (offs is read before the chunk loop)
+    }
+    if (STAMPS && tid == 0) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 7; ++i) { atomicAdd(&g_stamps[i], stamp_acc[i]); tot += stamp_acc[i]; }
+        atomicMax(&g_stamps[7], tot);                   // the slowest workgroup
+    }
+}
+
+// ----------------------------------------------------------------------------
+// tile kernel for sparse frames (class ids / ones): compact (voxel, frame) cells
+// ----------------------------------------------------------------------------
+// A batch of unrelated frames (SURVEY distribution A) puts ~5 records of a frame into a 4 x 4 x 8 tile: of the
+// 128 x 64 (voxel, frame) pairs of a tile only ~600 receive anything.  fuse_tiles_kernel walks such a tile in
+// chunks of a few frames with dense per-frame accumulators (46 barrier-delimited phases per tile, each with a
+// handful of busy lanes); this kernel takes ALL frames of the tile at once:
+//   mask    every record ORs its frame's bit into a 64-bit mask per voxel (one integer LDS atomic per corner);
+//   scan    cell index of (voxel v, frame f) = cellbase[v] + popcount(mask[v] & bits below f): the cells that
+//           exist are numbered densely, voxel-major, frames ascending inside a voxel;
+//   pass 1  W, S2 of every cell as 64-bit fixed-point integer atomics (exact, order independent);
+//   pass 2  one thread per voxel walks its cells from the last frame to the first (SUFFIX form of the unrolled
+//           blend, like fuse_dense_kernel):  m_n = (prod_f a_f) m_0 + sum_f t_f U_f,  t_f = g_f prod_{f' > f} a_f';
+//   pass 3  D[v][class] += t_f w^2 as 32-bit fixed point (31 fraction bits: every term and every sum of terms of
+//           a (voxel, class) lies in [0, 1 + eps]; a positive term below one unit adds one unit so that
+//           "non-zero" survives): integer atomics that return nothing;
+//   final   rows out: old * prod a + D, the old values having been loaded into registers at the start of the
+//           tile (they never enter LDS).
+// Seven barriers per tile, every pass over all records of the tile at once; the LDS image is ~53 KB at C = 54
+// (deltas 27 KB + 1,500 cells), so three 256-thread workgroups share a CU and one's memory phases overlap the
+// others' compute.  A tile whose frames need more cells than fit (tiles next to the cameras) takes its frames
+// in several windows; a later window multiplies the deltas by its own prod a.  Calls of more than 64 frames
+// take 64 at a time the same way.  All sums are integers: results are run-to-run identical.
+// tile_list_kernel picks this kernel or fuse_dense_kernel from the call's density; both work on 4 x 4 x 8 tiles.
+constexpr int CELLS_SV = 7;               // 4 x 4 x 8 tiles
+constexpr int CELLS_FX = 31;              // fraction bits of the deltas
+constexpr int CELLS_NT = 256;
+constexpr int CELLS_OVM = 8;              // float4s of the tile image a thread owns at most (C <= 64)
+constexpr int CELLS_MISC = 32;
+
+template <int KIND, int OVM, bool STAMPS = false>     // OVM: float4s of the tile image per thread (ceil(32 C / 256))
+__global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
+{
+    extern __shared__ float smem[];
+    unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    constexpr int NT = CELLS_NT, TV = 1 << CELLS_SV;
+    const int tid = threadIdx.x;
+    const int C = P.C, G = P.G, CAP = P.cells_cap;
+    const int m1 = (1 << P.s1) - 1;
+    const unsigned n_el = (unsigned)TV * (unsigned)C;
+    unsigned long long *cells = reinterpret_cast<unsigned long long *>(smem);  // [CAP + 1][2] W, S2; low word of W = t_f after pass 2
+    unsigned long long *mask = cells + (size_t)(CAP + 1) * 2;                   // [TV] frames of the window that touch the voxel
+    unsigned *Du = reinterpret_cast<unsigned *>(mask + TV);                     // [TV][C] deltas, units of 2^-CELLS_FX
+    float *atot = reinterpret_cast<float *>(Du + n_el);                         // [TV] prod a over the frames so far
+    int *cbase = reinterpret_cast<int *>(atot + TV);                            // [TV + 2] first cell of the voxel; [TV] = cells in use
+    int *misc = cbase + TV + 2;                                                 // look-up words (indices below)
+    constexpr int M_TILE = 0, M_NEXT = 1, M_FIT = 2, M_EA = 3, M_EB = 4, M_OFF = 6 /* [2] */, M_OFFN = 8 /* [2] */,
+                  M_CLS = 12 /* [TILE_CLASSES] */;
+    static_assert(M_CLS + TILE_CLASSES <= CELLS_MISC, "misc words");
+    const int fx_c = 182 - P.fx_shift;
+    const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
+    const float du_inv = __uint_as_float((unsigned)(127 - CELLS_FX) << 23);    // 2^-CELLS_FX
+    const float du_scale = __uint_as_float((unsigned)(127 + CELLS_FX) << 23);  // 2^CELLS_FX
+
+    if ((P.mode_force >= 0 ? P.mode_force : P.ticket[MODE_SLOT]) != MODE_CELLS) return;   // another tile kernel takes the call (uniform)
+    {
+        int listed = 0;
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) listed += P.ticket[1 + c];
+        if (listed == 0) return;
+    }
+    auto resolve = [&](int idx) {          // work list position -> tile id, -1 past the end
+        int tile_id = -1;
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) {
+            const int cc = misc[M_CLS + c];
+            if (tile_id < 0 && idx >= 0 && idx < cc) tile_id = P.active[c * P.n_tiles + idx];
+            idx -= cc;
+        }
+        return tile_id;
+    };
+    // first record of bucket k (after scatter_kernel cursor[k] is the END of bucket k)
+    auto bucket_start = [&](int k) { return k > 0 ? P.cursor[k - 1] : 0; };
+    // lane 0: first record of tile t, lane 1: one past its last (wave 0 only; tile ids below n_tiles by construction
+    // of the work list, so k <= n_tiles * G = n_keys and cursor[k - 1] is inside the scanned array)
+    auto tile_range = [&](int t) {
+        int o = 0;
+        if (t >= 0 && tid <= 1) o = bucket_start((t + tid) * G);
+        return o;
+    };
+    // Look-ups of the tiles ahead (work list entry -> record range: dependent global round trips) are made by
+    // wave 0 and advanced once per tile; the first four list positions of a workgroup are dealt statically
+    // (b, b + n, b + 2n, b + 3n: the list is heaviest first), tickets start at 4n (tile_list_kernel).
+    int idx_pend = -1, act_pend = -1, rng_tile = -1, rng_off = 0, nx_tile = -1, nx_off = 0;
+    if (tid == 0)
+#pragma unroll
+        for (int c = 0; c < TILE_CLASSES; ++c) misc[M_CLS + c] = P.ticket[1 + c];
+    for (int i = tid; i < (CAP + 1) * 2 + TV; i += NT) cells[i] = 0ull;          // cells and masks
+    for (unsigned i = tid; i < n_el; i += NT) Du[i] = 0u;
+    __syncthreads();
+    if (tid < 64) {
+        const int nb = gridDim.x, b = blockIdx.x;
+        const int t0 = resolve(b);
+        const int o0 = tile_range(t0);
+        if (tid == 0) misc[M_TILE] = t0;
+        if (tid <= 1) misc[M_OFF + tid] = o0;
+        nx_tile = resolve(b + nb);
+        nx_off = tile_range(nx_tile);
+        rng_tile = resolve(b + 2 * nb);
+        rng_off = tile_range(rng_tile);
+        act_pend = resolve(b + 3 * nb);
+        idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
+        idx_pend = __shfl(idx_pend, 0, 64);
+    }
+    __syncthreads();
+    int tile = misc[M_TILE];
+    if (tile < 0) return;
+
+    // the first EB x NT records of a tile are fetched one tile ahead and stay in registers for all passes
+    uint4 pre[EB], nxt[EB];
+    uint32_t prex[EB], nxtx[EB];
+    auto prefetch_entries = [&](int ta, int tb, uint4 (&q)[EB], uint32_t (&qx)[EB]) {
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
+            const int e = min(ta + tid + j * NT, tb - 1);
+            q[j] = P.rec[e];
+            qx[j] = KIND == 1 ? P.aux[e] : 0u;
+        }
+    };
+    auto tile_origin = [&](int t, int &o0, int &o1, int &o2) {
+        const int tz = t % P.nt2, ty = (t / P.nt2) % P.nt1, tx = t / (P.nt2 * P.nt1);
+        o0 = tx << P.s0; o1 = ty << P.s1; o2 = tz << P.s2;
+    };
+    const unsigned n4 = n_el >> 2, row_len = (unsigned)C << P.s2;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f *map4 = reinterpret_cast<v4f *>(P.map);
+    auto elem_index = [&](int t, unsigned q, size_t &g4) {  // float4 q of tile t -> float4 index in the map, false outside the map
+        int o0, o1, o2;
+        tile_origin(t, o0, o1, o2);
+        const unsigned i = q << 2;
+        const unsigned r = div_magic(i, P.magicC) >> P.s2;
+        const int l1 = r & m1, l0 = r >> P.s1;
+        g4 = ((((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len)) >> 2;
+        return q < n4 && o0 + l0 < P.size0 && o1 + l1 < P.size1;
+    };
+    // exclusive scan of the voxels' cell counts (wave 0, two voxels per lane)
+    auto scan_cells = [&]() {
+        if (tid < 64) {
+            const int n0 = __popcll(mask[2 * tid]), n1 = __popcll(mask[2 * tid + 1]);
+            int inc = n0 + n1;
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (tid >= o) inc += y; }
+            const int ex = inc - n0 - n1;
+            cbase[2 * tid] = ex;
+            cbase[2 * tid + 1] = ex + n0;
+            if (tid == 63) cbase[TV] = inc;
+        }
+    };
+
+    prefetch_entries(misc[M_OFF], misc[M_OFF + 1], pre, prex);
+    if (tid < TV) atot[tid] = 1.0f;
+
+    while (true) {
+        int o0, o1, o2;
+        tile_origin(tile, o0, o1, o2);
+        const int t_a = misc[M_OFF], t_b = misc[M_OFF + 1];
+        int tile_n = -1;
+        MF_STAMP(0)
+        // the tile's old rows: in flight during every pass, consumed by the final one
+        v4f oldv[OVM];
+#pragma unroll
+        for (int j = 0; j < OVM; ++j) {                    // unconditional: an element outside the map reads element 0
+            size_t g4;
+            const bool in = elem_index(tile, tid + j * NT, g4);
+            oldv[j] = map4[in ? g4 : 0];
+        }
+        // records [ea, eb) of the tile, EB x NT at a time, batches aligned to the tile's first record so that the
+        // first batch is always the register copy
+        auto for_records = [&](int ea, int eb, auto body) {
+            const int bb0 = t_a + (ea - t_a) / (NT * EB) * (NT * EB);
+            for (int bb = bb0; bb < eb; bb += NT * EB) {
+                uint4 r[EB];
+                uint32_t x[EB];
+                if (bb == t_a) {
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) { r[j] = pre[j]; x[j] = prex[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EB; ++j) {
+                        const int e = min(bb + tid + j * NT, eb - 1);
+                        r[j] = P.rec[e];
+                        x[j] = KIND == 1 ? P.aux[e] : 0u;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int e = bb + tid + j * NT;
+                    if (e >= ea && e < eb) body(r[j], x[j]);
+                }
+            }
+        };
+
+        int F = 0, win = 64;
+        bool first = true;
+        while (F < G) {                                     // windows of at most 64 frames whose cells fit
+            int Fe = min(F + win, G);
+            int ea = t_a, eb = t_b;
+            if (!(F == 0 && Fe == G)) {                     // part of the tile's frames: look its record range up
+                if (tid <= 1) misc[M_EA + tid] = bucket_start(tile * G + (tid == 0 ? F : Fe));
+                __syncthreads();
+                ea = misc[M_EA]; eb = misc[M_EA + 1];
+                __syncthreads();
+            }
+            if (ea < eb) {                                  // (uniform)
+                // ---- mask pass: which frames of the window touch which voxel
+                for_records(ea, eb, [&](const uint4 &r, uint32_t) {
+                    const unsigned long long bit = 1ull << (rec_group(r) - F);
+                    for_corners(P, r, o0, o1, o2, [&](int v, float) { atomicOr(&mask[v], bit); });
+                });
+                barrier_keep_vm();
+                MF_STAMP(1)
+                scan_cells();
+                barrier_keep_vm();
+                if (cbase[TV] > CAP) {                      // (uniform) the window's cells do not fit: take the frames that do
+                    if (tid < 64) {
+                        int cnt = 0;
+                        for (int v = 0; v < TV; ++v) cnt += (int)((mask[v] >> tid) & 1ull);   // cells of frame F + tid
+                        int inc = cnt;
+                        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (tid >= o) inc += y; }
+                        const int fit = __popcll(__ballot(inc <= CAP));          // inc is non-decreasing over the lanes
+                        if (tid == 0) misc[M_FIT] = fit < 1 ? 1 : fit;           // a frame has at most TV <= CAP cells
+                    }
+                    __syncthreads();
+                    const int n = misc[M_FIT];              // 1 <= n < 64 here
+                    Fe = F + n;
+                    win = n + (n >> 2) + 1;                 // the next window is sized by what fitted
+                    if (tid < TV) mask[tid] &= (1ull << n) - 1ull;
+                    if (tid == 0) misc[M_EB] = bucket_start(tile * G + Fe);
+                    __syncthreads();
+                    eb = misc[M_EB];
+                    scan_cells();
+                    __syncthreads();
+                }
+                MF_STAMP(2)
+                // ---- pass 1: W, S2 of every cell
+                for_records(ea, eb, [&](const uint4 &r, uint32_t) {
+                    const int fl = rec_group(r) - F;
+                    const unsigned long long below = (1ull << fl) - 1ull;
+                    for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                        const int ci = cbase[v] + __popcll(mask[v] & below);
+                        atomicAdd(&cells[2 * ci], to_fixed(w, fx_c));
+                        atomicAdd(&cells[2 * ci + 1], to_fixed(w * w, fx_c));
+                    });
+                });
+            }
+            if (first && tid < 64) {                        // advance the look-ups, once per tile
+                if (tid == 0) misc[M_NEXT] = nx_tile;
+                if (tid <= 1) misc[M_OFFN + tid] = nx_off;
+                nx_tile = rng_tile; nx_off = rng_off;
+                rng_tile = act_pend;
+                rng_off = tile_range(rng_tile);
+                act_pend = resolve(idx_pend);
+                idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
+                idx_pend = __shfl(idx_pend, 0, 64);
+            }
+            barrier_keep_vm();
+            MF_STAMP(3)
+            if (first) {
+                tile_n = misc[M_NEXT];
+                if (tile_n >= 0) prefetch_entries(misc[M_OFFN], misc[M_OFFN + 1], nxt, nxtx);   // the next tile's first records
+            }
+            if (ea < eb) {
+                // ---- pass 2: per voxel, cells from the last frame to the first: t_f = g_f * prod_{f' > f} a_f';
+                // prod a over the window multiplies what the earlier windows left
+                if (tid < TV) {
+                    const int v = tid, cs = cbase[v], ce = cbase[v + 1];
+                    float run = 1.0f;
+                    for (int j = ce - 1; j >= cs; --j) {
+                        const float rW = __builtin_amdgcn_rcpf((float)cells[2 * j] * fx_inv);
+                        const float a = 1.0f - P.iw * (((float)cells[2 * j + 1] * fx_inv) * rW);
+                        reinterpret_cast<float *>(cells + 2 * j)[0] = P.iw * rW * run;
+                        run *= a;
+                    }
+                    if (first) atot[v] = run;
+                    else if (ce > cs) {
+                        atot[v] *= run;
+                        for (int ch = 0; ch < C; ++ch) {
+                            const unsigned d = Du[v * C + ch];
+                            if (d != 0u) {
+                                unsigned nd = (unsigned)((double)d * (double)run);
+                                if (nd == 0u && run > 0.0f) nd = 1u;            // "non-zero" survives
+                                Du[v * C + ch] = nd;
+                            }
+                        }
+                    }
+                }
+                barrier_keep_vm();
+                MF_STAMP(4)
+                // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1)
+                for_records(ea, eb, [&](const uint4 &r, uint32_t x) {
+                    if (KIND == 1 && x >= (uint32_t)C) return;
+                    const int fl = rec_group(r) - F;
+                    const unsigned long long below = (1ull << fl) - 1ull;
+                    for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                        const int ci = cbase[v] + __popcll(mask[v] & below);
+                        const float term = (w * w) * klow(cells, 2 * ci);
+                        unsigned m = (unsigned)(term * du_scale);
+                        if (m == 0u && term > 0.0f) m = 1u;
+                        if (m != 0u) atomicAdd(&Du[KIND == 0 ? v : v * C + (int)x], m);
+                    });
+                });
+                barrier_keep_vm();
+                MF_STAMP(5)
+                // the window's cells and masks are cleared for the next window / tile
+                {
+                    const int used = cbase[TV];
+                    for (int i = tid; i < used * 2; i += NT) cells[i] = 0ull;
+                    if (tid < TV) mask[tid] = 0ull;
+                }
+            } else if (first && tid < TV) atot[tid] = 1.0f;
+            F = Fe;
+            first = false;
+            if (F < G) barrier_keep_vm();                   // the next window's mask pass ORs into cleared masks
+        }
+        // ---- the tile's rows go out: old * prod a + D (every row whole: an untouched voxel is rewritten with the
+        // value it had), and the deltas are cleared
+#pragma unroll
+        for (int j = 0; j < OVM; ++j) {
+            size_t g4;
+            const unsigned q = tid + j * NT;
+            if (elem_index(tile, q, g4)) {
+                const unsigned i = q << 2;
+                unsigned *d = Du + i;
+                v4f o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned v = div_magic(i + k, P.magicC);
+                    o[k] = oldv[j][k] * atot[v] + (float)d[k] * du_inv;
+                    d[k] = 0u;
+                }
+                map4[g4] = o;
+            }
+        }
+        MF_STAMP(6)
+        if (tile_n < 0) break;
+        tile = tile_n;
+#pragma unroll
+        for (int j = 0; j < EB; ++j) { pre[j] = nxt[j]; prex[j] = nxtx[j]; }
+        if (tid <= 1) misc[M_OFF + tid] = misc[M_OFFN + tid];
+        barrier_keep_vm();                                   // rows read, deltas / cells / masks clear, record range in place
     }
     if (STAMPS && tid == 0) {
         unsigned long long tot = 0;
@@ -1808,6 +2167,21 @@ __global__ void unproject_bin_kernel(FuseParams P, BinOut o)
 // ----------------------------------------------------------------------------
 static int ilog2_floor(unsigned x) { int l = 0; while ((2u << l) <= x) ++l; return l; }
 
+// Development knobs come from the environment.  A value outside [lo, hi] (or not a number) is ignored with one
+// line on stderr: nothing unchecked reaches a shift count, a thread count or an LDS size.
+static int env_int(const char *name, int lo, int hi, int dflt)
+{
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end != '\0' || v < lo || v > hi) {
+        fprintf(stderr, "[massfuse] %s=%s ignored (expected an integer in [%d, %d])\n", name, e, lo, hi);
+        return dflt;
+    }
+    return (int)v;
+}
+
 // Tile extents: the largest power-of-two voxel count whose LDS image (C floats of
 // deltas + scales + flag + four frames of 64-bit W/S2 accumulators per voxel) fits the
 // CU's LDS, capped at 512 voxels (8 x 8 x 8); z gets up to 8 so that HBM runs stay long.
@@ -1824,7 +2198,8 @@ static size_t dense_lds_bytes(int C, int gc)
 // kernels of the next batch).  MF_DENSE_GC overrides.
 static int dense_chunk_frames(int C, int G)
 {
-    static const int forced = getenv("MF_DENSE_GC") ? atoi(getenv("MF_DENSE_GC")) : 0;
+    static const int forced_raw = env_int("MF_DENSE_GC", 1, 64, 0);
+    static const int forced = forced_raw > 0 ? 1 << ilog2_floor((unsigned)forced_raw) : 0;     // a power of two (halved / doubled below)
     int gc = forced > 0 ? forced : 32;
     if (gc > 64) gc = 64;
     if (gc > G) gc = G;
@@ -1838,58 +2213,50 @@ static int dense_chunk_frames(int C, int G)
 // of the rows are checked when the kernel is launched: fuse_tiles_kernel works on any tile shape)
 static bool dense_shape_ok(const mf_grid *g, int G)
 {
-    static const bool on = !(getenv("MF_DENSE") && atoi(getenv("MF_DENSE")) == 0);
+    static const bool on = env_int("MF_DENSE", 0, 1, 1) != 0;
     if (!on || G < 2) return false;
     const int gc = dense_chunk_frames(g->channels, G);
     return dense_lds_bytes(g->channels, gc) <= 160 * 1024 && (G + gc - 1) / gc <= DENSE_MAX_CHUNKS &&
            ((size_t)g->channels << DENSE_SV) / 4 <= 4 * 512;
 }
 
-// What the previous call on a workspace counted decides the tile shape of the next one: the density of a
-// trajectory changes slowly, and the shape has to be fixed before the points are bucketed.  After its
-// tile_list_kernel a call copies two words (records, threshold) to pinned host memory; the next call on
-// the same workspace reads them if the copy has finished.  MF_DENSE=1 forces the dense shape, 0 forbids it.
-struct TileHint {
-    hipEvent_t ev = nullptr;
-    int *host = nullptr;
-    bool pending = false;
-    bool dense = false;        // what the last finished call measured
-    bool staged_dense = false; // shape of the batch staged last (a commit on its own must use the same)
-};
-static std::mutex g_hint_mu;
-static std::unordered_map<const void *, TileHint> g_hints;
-
-static bool tile_hint(const void *ws)
+// fuse_cells_kernel: cap + 1 cells of 16 bytes, a mask per voxel, 4-byte deltas, prod a, cell bases, look-up words
+static size_t cells_lds_bytes(int C, int cap)
 {
-    static const int forced = getenv("MF_DENSE") ? atoi(getenv("MF_DENSE")) : -1;
-    if (forced == 1) return true;
-    if (forced == 0 || !ws) return false;
-    std::lock_guard<std::mutex> lock(g_hint_mu);
-    auto it = g_hints.find(ws);
-    if (it == g_hints.end()) return false;
-    TileHint &h = it->second;
-    if (h.pending && hipEventQuery(h.ev) == hipSuccess) {
-        h.pending = false;
-        h.dense = h.host[0] >= h.host[1] && h.host[0] > 0;
-    }
-    return h.dense;
+    const size_t TV = (size_t)1 << CELLS_SV;
+    return (size_t)(cap + 1) * 16 + TV * 8 + TV * C * 4 + TV * 4 + (TV + 2) * 4 + CELLS_MISC * 4;
 }
 
-static void tile_hint_post(const void *ws, const int *dev_words, hipStream_t st)
+// Workgroups of fuse_cells_kernel per CU and the cells each of them holds: as many workgroups as leave each at
+// least 1,100 cells (a tile of a batch of unrelated frames needs ~600), eight at most (256 threads each).
+static bool cells_config(int C, int lds_per_cu, int &cap, int &per_cu)
 {
-    std::lock_guard<std::mutex> lock(g_hint_mu);
-    TileHint &h = g_hints[ws];
-    if (!h.ev) {
-        if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) { h.ev = nullptr; return; }
-        if (hipHostMalloc((void **)&h.host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) { h.host = nullptr; return; }
-        h.host[0] = h.host[1] = 0;
+    static const int forced = env_int("MF_CELLS_PER_CU", 1, 8, 0);            // dev
+    if (((size_t)C << CELLS_SV) / 4 > (size_t)CELLS_OVM * CELLS_NT) return false;   // the tile image in a thread's float4 registers
+    const size_t fixed = cells_lds_bytes(C, 0);
+    for (per_cu = forced > 0 ? forced : 8; per_cu >= 1; --per_cu) {
+        const size_t budget = ((size_t)lds_per_cu / per_cu) & ~(size_t)1023;   // LDS is handed out in blocks
+        const size_t want = forced > 0 || per_cu == 1 ? (size_t)((1 << CELLS_SV) + 1) * 16 : (size_t)1100 * 16;
+        if (budget < fixed + want) { if (forced > 0) return false; continue; }
+        cap = (int)((budget - fixed) / 16) - 1;
+        return cap >= (1 << CELLS_SV);          // a single frame's cells (one per voxel at most) always fit
     }
-    if (!h.host || h.pending) return;            // one copy in flight at a time
-    if (hipMemcpyAsync(h.host, dev_words, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return;
-    if (hipEventRecord(h.ev, st) == hipSuccess) h.pending = true;
+    return false;
+}
+
+// May a call of G sequential frames of class ids / ones onto this grid be bucketed on 4 x 4 x 8 tiles, for
+// fuse_dense_kernel / fuse_cells_kernel (tile_list_kernel picks one of them from the call's density)?  Decided
+// from the call's arguments alone, so a stage / commit pair and a repeated run agree.
+static bool int_tiles_ok(const mf_grid *g, int G, int feat_kind)
+{
+    if (feat_kind == MF_FEAT_DENSE_F32 || !dense_shape_ok(g, G)) return false;
+    return (uintptr_t)g->map % 16 == 0 && g->size2 % 8 == 0 &&
+           (size_t)g->size0 * g->size1 * g->size2 * g->channels < ((size_t)1 << 34);
 }
 
 static int g_gc_override = -1;
+// MF_TILE="s0 s1 s2 threads [gc]": log2 tile extents (each 0..4, at most 512 voxels in all), workgroup size (a
+// multiple of 64 up to 1024) and frames per chunk (1..MAX_CHUNK).  Anything else is ignored as a whole.
 static bool tile_override(int &s0, int &s1, int &s2, int &nt)
 {
     static int v[5] = {-1, -1, -1, -1, -1};
@@ -1897,8 +2264,14 @@ static bool tile_override(int &s0, int &s1, int &s2, int &nt)
     if (!parsed) {
         parsed = true;
         const char *e = getenv("MF_TILE");
-        have = e && sscanf(e, "%d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4]) >= 4;
-        g_gc_override = have ? v[4] : -1;
+        const int n = e ? sscanf(e, "%d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4]) : 0;
+        have = n >= 4 && v[0] >= 0 && v[0] <= 4 && v[1] >= 0 && v[1] <= 4 && v[2] >= 0 && v[2] <= 4 &&
+               v[0] + v[1] + v[2] <= 9 && v[3] >= 64 && v[3] <= 1024 && v[3] % 64 == 0 &&
+               (n < 5 || (v[4] >= 1 && v[4] <= MAX_CHUNK));
+        if (e && *e && !have)
+            fprintf(stderr, "[massfuse] MF_TILE=\"%s\" ignored (expected \"s0 s1 s2 threads [gc]\": log2 extents 0..4 each, "
+                            "sum <= 9, threads a multiple of 64 in [64, 1024], gc in [1, %d])\n", e, MAX_CHUNK);
+        g_gc_override = have && n >= 5 ? v[4] : -1;
     }
     if (have) { s0 = v[0]; s1 = v[1]; s2 = v[2]; nt = v[3]; }
     return have;
@@ -1967,18 +2340,18 @@ struct Layout {
 // records; MF_SPLIT_MIN / MF_SPLIT_PART override them for experiments
 static int split_min()
 {
-    static const int v = getenv("MF_SPLIT_MIN") ? atoi(getenv("MF_SPLIT_MIN")) : 8192;
-    return v > 64 ? v : 64;
+    static const int v = env_int("MF_SPLIT_MIN", 64, 1 << 28, 8192);
+    return v;
 }
 static int split_part()
 {
-    static const int v = getenv("MF_SPLIT_PART") ? atoi(getenv("MF_SPLIT_PART")) : 4096;
-    return v > 64 ? v : 64;
+    static const int v = env_int("MF_SPLIT_PART", 64, 1 << 28, 4096);
+    return v;
 }
 
 static bool split_enabled()
 {
-    static const bool on = !(getenv("MF_SPLIT") && atoi(getenv("MF_SPLIT")) == 0);
+    static const bool on = env_int("MF_SPLIT", 0, 1, 1) != 0;
     return on;
 }
 
@@ -2111,20 +2484,10 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (P.G < 1 || P.G > MAX_GROUPS)
         return fail(MF_ERR_INVALID, "at most %d sequential frames per call, got %d", MAX_GROUPS, P.G);
     if (P.n_points == 0) return MF_OK;
-    // tile shape: 4 x 4 x 8 when the previous call on this workspace found the scene dense; a commit on its
-    // own takes what its staging call took
-    bool dense_tiles;
-    if (phase == 2) {
-        std::lock_guard<std::mutex> lock(g_hint_mu);
-        auto it = g_hints.find(workspace);
-        dense_tiles = it != g_hints.end() && it->second.staged_dense;
-    } else {
-        dense_tiles = FRONT == 0 && P.G >= 2 && tile_hint(workspace) && dense_shape_ok(grid, P.G);
-        if (FRONT == 0 && P.G >= 2) {
-            std::lock_guard<std::mutex> lock(g_hint_mu);
-            g_hints[workspace].staged_dense = dense_tiles;
-        }
-    }
+    // tile shape: 4 x 4 x 8 for sequential frames of class ids / ones (the all-integer tile kernels), else by
+    // the LDS budget of fuse_tiles_kernel; a function of the arguments only (a commit on its own agrees with its
+    // staging call, a repeated run with itself)
+    const bool dense_tiles = FRONT == 0 && P.G >= 2 && int_tiles_ok(grid, P.G, P.feat_kind);
     choose_tile(grid, P.G, dense_tiles, P.s0, P.s1, P.s2);
     Layout L;
     if (!make_layout(grid, P.n_points, P.G, P.s0, P.s1, P.s2, L, P.nt0, P.nt1, P.nt2))
@@ -2175,16 +2538,17 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
     int blocks = dev.cus * per_cu;
-    { static const int cap = getenv("MF_BLOCKS") ? atoi(getenv("MF_BLOCKS")) : 0; if (cap > 0 && blocks > cap) blocks = cap; }   // dev: fewer workgroups
+    static const int blocks_cap = env_int("MF_BLOCKS", 1, 1 << 20, 0);          // dev: fewer workgroups
+    if (blocks_cap > 0 && blocks > blocks_cap) blocks = blocks_cap;
     if (blocks > P.n_tiles) blocks = P.n_tiles;
     // the all-integer tile kernel (class ids / ones, float4 rows, 4 x 4 x 8 tiles): launched next to the tile
     // kernel when the call was bucketed on its tiles; tile_list_kernel decides on the device which of the two runs
-    static const int dense_nt = getenv("MF_DENSE_NT") ? atoi(getenv("MF_DENSE_NT")) : 512;
+    static const int dense_nt = env_int("MF_DENSE_NT", 512, 1024, 512);      // 512 or 1024 (anything between counts as 512)
     static const bool dense_forced = getenv("MF_DENSE_FORCE") != nullptr;      // dev / tests: the dense kernel whatever the density
     const int dgc = dense_chunk_frames(P.C, P.G);
     const size_t dlds = dense_lds_bytes(P.C, dgc);
     // (a merged batch of several frames is one group on 4 x 4 x 8 tiles anyway: the kernel is offered to it too)
-    static const int dense_min_frames = getenv("MF_DENSE_MIN_FRAMES") ? atoi(getenv("MF_DENSE_MIN_FRAMES")) : 2;   // dev
+    static const int dense_min_frames = env_int("MF_DENSE_MIN_FRAMES", 1, 1 << 20, 2);   // dev
     const bool merged_batch = FRONT == 0 && P.G == 1 && P.n_frames >= dense_min_frames;
     const bool use_dense = (dense_tiles || merged_batch) && sv == DENSE_SV && P.s2 == 3 && P.feat_kind != MF_FEAT_DENSE_F32 && P.vec4 &&
                        dlds <= (size_t)dev.lds_per_cu && (P.G + dgc - 1) / dgc <= DENSE_MAX_CHUNKS;
@@ -2193,8 +2557,18 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (dper > 2048 / dnt) dper = 2048 / dnt;
     if (dper < 1) dper = 1;
     int blocks_dense = dev.cus * dper;
-    { static const int cap = getenv("MF_BLOCKS") ? atoi(getenv("MF_BLOCKS")) : 0; if (cap > 0 && blocks_dense > cap) blocks_dense = cap; }
+    if (blocks_cap > 0 && blocks_dense > blocks_cap) blocks_dense = blocks_cap;
     if (blocks_dense > P.n_tiles) blocks_dense = P.n_tiles;
+    // the compact-cell tile kernel for sparse frames (same tiles, same feature kinds, sequential frames only);
+    // MF_CELLS=0 keeps it out, MF_CELLS_FORCE gives it every call it is offered (dev / tests)
+    static const bool cells_on = env_int("MF_CELLS", 0, 1, 1) != 0;
+    static const bool cells_forced = getenv("MF_CELLS_FORCE") != nullptr;
+    int cells_cap = 0, cells_per_cu = 1;
+    const bool use_cells = cells_on && dense_tiles && sv == CELLS_SV && P.s2 == 3 && P.s0 == 2 && P.vec4 && P.G >= 2 &&
+                           cells_config(P.C, dev.lds_per_cu, cells_cap, cells_per_cu);
+    int blocks_cells = dev.cus * cells_per_cu;
+    if (blocks_cap > 0 && blocks_cells > blocks_cap) blocks_cells = blocks_cap;
+    if (blocks_cells > P.n_tiles) blocks_cells = P.n_tiles;
 
     if (phase & 1) {
     prof_mark(0, st);
@@ -2218,9 +2592,10 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
                        P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
                        (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks,
-                       use_dense ? (1 << sv) | (dense_forced ? 1 << 20 : 0) : 0, 4 * blocks_dense);
+                       (use_dense || use_cells ? 1 << sv : 0) | (use_dense ? 1 << 20 : 0) | (use_cells ? 1 << 21 : 0) |
+                           (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0),
+                       4 * blocks_dense, 4 * blocks_cells);
     MF_LAUNCH_CHECK("tile_list_kernel");
-    if (FRONT == 0 && P.G >= 2 && phase != 2) tile_hint_post(workspace, P.ticket + HINT_SLOT, st);
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
@@ -2262,6 +2637,11 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         T.fx_shift = 62 - bits; if (T.fx_shift > 50) T.fx_shift = 50;
     }
     T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
+    T.ctr = P.ticket;
+    T.cells_cap = cells_cap;
+    // the all-integer kernels bound every term by 1, which needs 0 <= iw <= 1; any other blend weight (the
+    // reference accepts it) is taken by fuse_tiles_kernel, on whatever tiles the call was bucketed
+    T.mode_force = (P.iw >= 0.0f && P.iw <= 1.0f) ? -1 : MODE_TILES;
     // with ones features every tile of a single-group call goes to the single-pass kernel (tile_list_kernel,
     // min_mean = 0): nothing is listed for the tile kernel, whose launch is skipped
     if (!(single && P.feat_kind == MF_FEAT_ONES)) {
@@ -2286,8 +2666,32 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         }
         TileParams S = T;
         S.gc = dgc;
+        S.ctr = P.ticket + TICKET_DENSE;
         hipLaunchKernelGGL(dk, dim3(blocks_dense), dim3(dnt), dlds, st, S);   // returns at once unless tile_list_kernel chose it
         MF_LAUNCH_CHECK("fuse_dense_kernel");
+    }
+    if (use_cells) {
+        const int ovm = (int)((((size_t)P.C << CELLS_SV) / 4 + CELLS_NT - 1) / CELLS_NT);
+        void (*ck)(TileParams);
+        if (kind == 0) ck = stamps ? fuse_cells_kernel<0, 1, true> : fuse_cells_kernel<0, 1>;
+        else if (ovm <= 4) ck = stamps ? fuse_cells_kernel<1, 4, true> : fuse_cells_kernel<1, 4>;
+        else if (ovm <= 7) ck = stamps ? fuse_cells_kernel<1, 7, true> : fuse_cells_kernel<1, 7>;
+        else ck = stamps ? fuse_cells_kernel<1, 8, true> : fuse_cells_kernel<1, 8>;
+        const size_t clds = cells_lds_bytes(P.C, cells_cap);
+        {
+            static std::mutex mu4;
+            static std::unordered_map<const void *, size_t> granted4;
+            std::lock_guard<std::mutex> lock(mu4);
+            size_t &have = granted4[(const void *)ck];
+            if (have < clds) {
+                MF_HIP_CHECK(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+                have = clds;
+            }
+        }
+        TileParams S = T;
+        S.ctr = P.ticket + TICKET_CELLS;
+        hipLaunchKernelGGL(ck, dim3(blocks_cells), dim3(CELLS_NT), clds, st, S);   // returns at once unless tile_list_kernel chose it
+        MF_LAUNCH_CHECK("fuse_cells_kernel");
     }
     if (single) {
         SingleParams S;
@@ -2330,6 +2734,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         fprintf(stderr, "[MF_STAMPS] blocks=%d nt=%d lds=%zu gc=%d | ticket+offs %.1f%% setup %.1f%% chunk-zero %.1f%% P1 %.1f%% P2 %.1f%% P3 %.1f%% final %.1f%% | total %.3g ticks/block\n",
                 blocks, nt, lds, P.gc, 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot,
                 100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot, tot / blocks);
+        if (z[7] && use_cells) fprintf(stderr, "[MF_STAMPS] cells kernel (if it ran): %d workgroups, cap %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% mask %.1f%% scan %.1f%% pass1 %.1f%% pass2 %.1f%% pass3 %.1f%% final %.1f%%\n",
+                          blocks_cells, cells_cap, tot / blocks_cells, (double)z[7], 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot, 100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot);
         if (z[7]) fprintf(stderr, "[MF_STAMPS] dense kernel: %d workgroups, gc %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% barrier %.1f%% pass1 %.1f%% look-ups+barrier %.1f%% fetch issue %.1f%% pass2 %.1f%% pass3 %.1f%%\n", blocks_dense, dgc,
                           tot / blocks_dense, (double)z[7], 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[6] / tot, 100 * z[2] / tot, 100 * z[5] / tot, 100 * z[3] / tot, 100 * z[4] / tot);
     }
@@ -2368,7 +2774,22 @@ int mf_profile_read(int32_t call, float *ms)
     return g_prof_calls;
 }
 
-int mf_fuse_tile_hint(const void *workspace) { return tile_hint(workspace) ? 1 : 0; }
+int mf_fuse_last_mode(const mf_grid *grid, int64_t n_points, int32_t n_groups, const void *workspace, void *stream)
+{
+    if (check_grid(grid, false) != MF_OK) return MF_ERR_INVALID;
+    if (!workspace || n_points < 1 || n_groups < 1 || n_groups > MAX_GROUPS) return fail(MF_ERR_INVALID, "bad argument");
+    int s0, s1, s2, a, b, c;
+    // the layout of a call of frames (front end 0) with these arguments; class-id / ones kinds (the only ones
+    // with a choice of tile kernel)
+    choose_tile(grid, n_groups, n_groups >= 2 && int_tiles_ok(grid, n_groups, MF_FEAT_ONES), s0, s1, s2);
+    Layout L;
+    if (!make_layout(grid, n_points, n_groups, s0, s1, s2, L, a, b, c)) return fail(MF_ERR_INVALID, "problem too large");
+    int mode = -1;
+    MF_HIP_CHECK(hipMemcpyAsync(&mode, (const char *)workspace + L.ticket + MODE_SLOT * sizeof(int), sizeof(int),
+                                hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return mode;
+}
 
 size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int32_t n_groups)
 {

@@ -41,6 +41,27 @@ def build(force=False):
 _lib = None
 
 
+def _default_threads():
+    """Threads of the blend loop (bit-identical results for any count, see massref.c): MASSREF_THREADS, else
+    the CPUs this process may use, at most 32."""
+    env = os.environ.get("MASSREF_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 32))
+
+
+def set_threads(n):
+    lib().ref_set_threads(int(n))
+
+
+def get_threads():
+    return lib().ref_get_threads()
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -61,6 +82,10 @@ def lib():
         L.ref_update_feature_map.restype = i64
         L.ref_pairwise_l2.argtypes = [f32p, i64, f32p, i64, i64, f32p]
         L.ref_pairwise_l2.restype = None
+        L.ref_set_threads.argtypes = [ctypes.c_int]
+        L.ref_set_threads.restype = None
+        L.ref_get_threads.restype = ctypes.c_int
+        L.ref_set_threads(_default_threads())
         _lib = L
     return _lib
 

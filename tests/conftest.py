@@ -85,3 +85,17 @@ def assert_map_close_device(got, want, rtol=1e-4, atol=1e-6, what="map", slab=32
                                      f"max abs err {float(err.max()):.3e}")
         occupied += int((w != 0).any(-1).sum())
     return occupied
+
+
+def last_fuse_mode(layer, n_frames, workspace=None):
+    """Which tile kernel took the most recent sequential multi-frame call on `layer` (its own workspace
+    unless one is given): mass_amd._lib.MODE_TILES / MODE_DENSE / MODE_CELLS.  Waits for the stream."""
+    from mass_amd import _lib
+    from mass_amd.utils.projection import _grid_struct
+    g = _grid_struct(layer.data, layer.bins_x, layer.bins_y, layer.bins_z)
+    n_points = n_frames * layer.rays.shape[0] * layer.rays.shape[1]
+    ws = workspace if workspace is not None else layer._workspace
+    wptr, _ = ws.get(1, layer.data.device)
+    mode = _lib.lib.mf_fuse_last_mode(g, n_points, n_frames, wptr, _lib.current_stream(layer.data.device))
+    assert mode >= 0, _lib.lib.mf_last_error()
+    return mode

@@ -1,14 +1,14 @@
 """Real-scene batches (SURVEY 8(d) distribution B): the all-integer tile kernel on 4x4x8 tiles.
 
-A multi-frame call picks its tile shape from the density the previous call on the same workspace
-measured (include/massfuse.h, mf_fuse_frames), so the second batch of a room trajectory runs in
-fuse_dense_kernel.  Both batches are checked against the oracle loop of layer.update() calls
-(base_projection_layer.py:282-343); the oracle is the C restatement pinned by the reference's fixtures."""
+Sequential frames of class ids / ones are bucketed on 4x4x8 tiles and tile_list_kernel picks the tile
+kernel from the call's own density (include/massfuse.h, mf_fuse_frames): a room trajectory runs in
+fuse_dense_kernel from the first batch on.  Batches are checked against the oracle loop of layer.update()
+calls (base_projection_layer.py:282-343); the oracle is the C restatement pinned by the reference's fixtures."""
 import numpy as np
 import pytest
 import torch
 
-from conftest import assert_map_close
+from conftest import assert_map_close, assert_map_close_device, last_fuse_mode
 
 pytestmark = pytest.mark.gpu
 H, W, MAP, C = 120, 160, 96, 7
@@ -47,9 +47,7 @@ def test_room_batches_take_the_dense_kernel_and_match_the_oracle(device, kind):
             ref.update(dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t],
                             depth=tr["depth"][t], features=feats))
         assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"{kind} batch {half}")
-        wptr, _ = lay._workspace.get(1, lay.data.device)
-        hint = _lib.lib.mf_fuse_tile_hint(wptr)
-        assert hint == 1, "a room batch is dense: the next call on this workspace takes the 4x4x8 tiles"
+        assert last_fuse_mode(lay, n) == _lib.MODE_DENSE, "a room batch is dense: fuse_dense_kernel takes it"
 
 
 def test_dense_kernel_is_run_to_run_identical(device):
@@ -64,9 +62,8 @@ def test_dense_kernel_is_run_to_run_identical(device):
                               depth=tr["depth"][sl], semantic=tr["semantic"][sl]), sequential=True)
         torch.cuda.synchronize()
 
-    run(slice(0, 8))                                     # measures the density: the next calls take the dense path
-    wptr, _ = lay._workspace.get(1, lay.data.device)
-    assert _lib.lib.mf_fuse_tile_hint(wptr) == 1
+    run(slice(0, 8))
+    assert last_fuse_mode(lay, 8) == _lib.MODE_DENSE
     outs = []
     for _ in range(2):
         lay.reset()
@@ -103,15 +100,12 @@ def test_dense_kernel_three_chunks_vs_oracle(device, iw):
                             depth=tr["depth"][t],
                             features=torch.nn.functional.one_hot(tr["semantic"][t].long(), c).float()))
         assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"iw {iw} batch {half}")
-    wptr, _ = lay._workspace.get(1, lay.data.device)
-    assert _lib.lib.mf_fuse_tile_hint(wptr) == 1
+    assert last_fuse_mode(lay, n) == _lib.MODE_DENSE
 
 
-def test_pipelined_room_batches_switch_tile_shape_midstream(device):
-    """FusePipeline (stage on a side stream, commit in order, two workspaces) over a room trajectory: the density
-    words of the first batches arrive while later ones are being staged, so the tile shape changes from 8x8x8 to
-    4x4x8 somewhere in the stream, per workspace; a commit must use what its own staging used.  Checked against
-    the oracle loop."""
+def test_pipelined_room_batches(device):
+    """FusePipeline (stage on a side stream, commit in order, two workspaces) over a room trajectory, checked
+    against the oracle loop; every batch runs in fuse_dense_kernel."""
     from mass_amd import _lib
     from mass_amd.episodes import room_trajectory
     from mass_amd.utils.projection import FusePipeline
@@ -124,12 +118,9 @@ def test_pipelined_room_batches_switch_tile_shape_midstream(device):
         poses = lay._poses(tr["position"][sl], tr["yaw"][sl], tr["elevation"][sl])
         pipe.submit(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, tr["depth"][sl].to(device).reshape(per, H, W),
                     tr["semantic"][sl].to(device), lay.data, interpolation_weight=lay.interpolation_weight, sequential=True)
-        if b == 2:
-            torch.cuda.synchronize()                     # by now both workspaces have measured a dense batch
     pipe.flush()
     torch.cuda.synchronize()
-    hints = [_lib.lib.mf_fuse_tile_hint(ws.get(1, lay.data.device)[0]) for ws in pipe.ws]
-    assert hints == [1, 1]
+    assert [last_fuse_mode(lay, per, ws) for ws in pipe.ws] == [_lib.MODE_DENSE, _lib.MODE_DENSE]
     for t in range(nb * per):
         ref.update(dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t], depth=tr["depth"][t],
                         features=torch.nn.functional.one_hot(tr["semantic"][t].long(), C).float()))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, assert_map_close_device
+from conftest import ROOT, assert_map_close_device, last_fuse_mode
 
 pytestmark = pytest.mark.gpu
 
@@ -34,11 +34,76 @@ def test_headline_launch_64_frames_vs_oracle(device):
     lay = SemanticProjectionLayer(feature_size=C, **KW).to(device)
     lay.update_batch(dict(position=fr["position"], yaw=fr["yaw"], elevation=fr["elevation"],
                           depth=fr["depth"].to(device), semantic=fr["semantic"].to(device)), sequential=True)
+    from mass_amd import _lib
+    assert last_fuse_mode(lay, n) == _lib.MODE_CELLS, "unrelated frames are sparse: fuse_cells_kernel takes the launch"
     ref = orc.RefProjectionLayer(feature_size=C, **KW)
     for t in range(n):
         ref.update(oracle_obs(fr, t))
     occupied = assert_map_close_device(lay.data, ref.data, what=f"{n} frames sequential")
     assert occupied > 900_000 * min(n, 8)
+
+
+@pytest.mark.parametrize("kind,iw,batches", [("label", 0.5, 2), ("label", 1.0, 1), ("ones", 0.5, 2)])
+def test_room_batches_fullsize_dense_kernel_vs_oracle(device, kind, iw, batches):
+    """The kernel behind the room-batch rate at ITS shape: 480x640 -> 256^3 x 54, sequential
+    batches of 34 room frames through fuse_dense_kernel (two chunks of 32 + 2 frames per tile, the second
+    batch blends onto the first), each against the oracle loop; also iw = 1 and the occupancy (ones) map."""
+    from oracle import massref as orc
+    from mass_amd import _lib
+    from mass_amd.episodes import room_trajectory
+    from mass_amd.nn.applications.occupancy_projection_layer import OccupancyProjectionLayer
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    n = 34
+    tr = room_trajectory(batches * n, H, W, seed=2)
+    kw = dict(KW, interpolation_weight=iw)
+    if kind == "label":
+        lay = SemanticProjectionLayer(feature_size=C, **kw).to(device)
+        ref = orc.RefProjectionLayer(feature_size=C, **kw)
+    else:
+        lay = OccupancyProjectionLayer(**kw).to(device)
+        ref = orc.RefProjectionLayer(feature_size=1, **kw)
+    for b in range(batches):
+        sl = slice(b * n, (b + 1) * n)
+        batch = dict(position=tr["position"][sl], yaw=tr["yaw"][sl], elevation=tr["elevation"][sl],
+                     depth=tr["depth"][sl].to(device))
+        if kind == "label":
+            batch["semantic"] = tr["semantic"][sl].to(device)
+        lay.update_batch(batch, sequential=True)
+        assert last_fuse_mode(lay, n) == _lib.MODE_DENSE
+        for t in range(sl.start, sl.stop):
+            feats = (torch.nn.functional.one_hot(tr["semantic"][t].long(), C).float() if kind == "label"
+                     else torch.ones(H, W, 1))
+            ref.update(dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t],
+                            depth=tr["depth"][t], features=feats))
+        occupied = assert_map_close_device(lay.data, ref.data, what=f"{kind} iw {iw} room batch {b}")
+        assert occupied > 20_000
+
+
+def test_pipelined_headline_batches_fullsize_vs_oracle(device):
+    """The issue path bench.py times: FusePipeline submit / flush (stage on the side stream, commit
+    alone on the main one) of two 24-frame distribution-A batches at 480x640 -> 256^3 x 54, against the oracle."""
+    from oracle import massref as orc
+    from mass_amd import _lib
+    from mass_amd.episodes import dist_a_frames
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    from mass_amd.utils.projection import FusePipeline
+    n, nb = 24, 2
+    fr = dist_a_frames(n * nb, seed0=300, height=H, width=W)
+    lay = SemanticProjectionLayer(feature_size=C, **KW).to(device)
+    pipe = FusePipeline(device)
+    for b in range(nb):
+        sl = slice(b * n, (b + 1) * n)
+        poses = lay._poses(fr["position"][sl], fr["yaw"][sl], fr["elevation"][sl])
+        pipe.submit(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, fr["depth"][sl].to(device).reshape(n, H, W),
+                    fr["semantic"][sl].to(device), lay.data, interpolation_weight=lay.interpolation_weight,
+                    sequential=True)
+    pipe.flush()
+    torch.cuda.synchronize()
+    assert [last_fuse_mode(lay, n, ws) for ws in pipe.ws] == [_lib.MODE_CELLS, _lib.MODE_CELLS]
+    ref = orc.RefProjectionLayer(feature_size=C, **KW)
+    for t in range(n * nb):
+        ref.update(oracle_obs(fr, t))
+    assert_map_close_device(lay.data, ref.data, what="pipelined distribution-A batches")
 
 
 @pytest.mark.parametrize("n", [4, 8])

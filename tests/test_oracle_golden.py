@@ -155,3 +155,30 @@ def test_config1_digest():
         assert float(d.double().sum()) == pytest.approx(want["sum"], rel=1e-12)
         assert float(d.max()) == want["max"]
     assert want["occupied"] == 296167      # SURVEY / BASELINE.md anchor
+
+
+def test_threaded_blend_is_bit_identical_to_the_single_thread():
+    """oracle/massref.c may run its blend loop on several threads (each owns a fixed subset of the touched
+    voxels and keeps the single-thread visiting order): same bits for 1, 3 and 8 threads, on a map that is
+    not zero and with points that pile onto the same voxels."""
+    g = torch.Generator().manual_seed(4)
+    kw = dict(camera_height=60, camera_width=80, map_height=40, map_width=40, map_depth=24, feature_size=7,
+              grid_resolution=0.1)
+    init = torch.rand(40, 40, 24, 7, generator=g)
+    obs = [dict(position=0.2 * torch.randn(3, generator=g), yaw=float(6.28 * torch.rand((), generator=g)),
+                elevation=-0.4, depth=0.3 + 1.2 * torch.rand(60, 80, 1, generator=g),
+                features=torch.rand(60, 80, 7, generator=g)) for _ in range(3)]
+    before = orc.get_threads()
+    outs = []
+    try:
+        for n in (1, 3, 8):
+            orc.set_threads(n)
+            lay = orc.RefProjectionLayer(**kw)
+            lay.data.copy_(init)
+            for o in obs:
+                lay.update(o)
+            outs.append(lay.data.clone())
+    finally:
+        orc.set_threads(before)
+    assert bool((outs[0] != init).any())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
