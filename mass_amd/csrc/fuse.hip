@@ -1402,8 +1402,57 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
 constexpr int CELLS_SV = 7;               // 4 x 4 x 8 tiles
 constexpr int CELLS_FX = 31;              // fraction bits of the deltas
 constexpr int CELLS_NT = 256;
+#ifndef CELLS_EB_DEF
+#define CELLS_EB_DEF 2
+#endif
+constexpr int CELLS_EB = CELLS_EB_DEF;    // records per thread fetched a tile ahead and kept in registers
 constexpr int CELLS_OVM = 8;              // float4s of the tile image a thread owns at most (C <= 64)
 constexpr int CELLS_MISC = 32;
+
+// The 8 corners of a record on a 4 x 4 x 8 tile, visited by a ROLLED loop: per-axis tile-local coordinates and
+// weights are computed once, a corner picks its three by the bits of its number (uniform selects).  The unrolled
+// visitor of fuse_tiles_kernel (for_corners_idx) keeps all eight corners' values live at once (~130 VGPRs in
+// this kernel's passes, with spills at three waves per SIMD); rolled, a pass needs ~40.
+struct CellFoot { unsigned l0, h0, l1, h1, l2, h2; float wl0, wh0, wl1, wh1, wl2, wh2; };
+
+__device__ __forceinline__ CellFoot cell_foot(const TileParams &P, const uint4 &r, int o0, int o1, int o2)
+{
+    const int k0 = r.x & 1023, k1 = (r.x >> 10) & 1023, k2 = (r.x >> 20) & 1023;
+    const unsigned rm = 0x3fffffffu;                // sequential frames: the two top bits of each word carry the frame
+    const AxisFoot a0 = axis_foot(k0, __uint_as_float(r.y & rm), P.size0);
+    const AxisFoot a1 = axis_foot(k1, __uint_as_float(r.z & rm), P.size1);
+    const AxisFoot a2 = axis_foot(k2, __uint_as_float(r.w & rm), P.size2);
+    CellFoot f;
+    f.l0 = (unsigned)(a0.lo - o0); f.h0 = (unsigned)(a0.hi - o0);
+    f.l1 = (unsigned)(a1.lo - o1); f.h1 = (unsigned)(a1.hi - o1);
+    f.l2 = (unsigned)(a2.lo - o2); f.h2 = (unsigned)(a2.hi - o2);
+    f.wl0 = a0.wlo; f.wh0 = a0.whi; f.wl1 = a1.wlo; f.wh1 = a1.whi; f.wl2 = a2.wlo; f.wh2 = a2.whi;
+    return f;
+}
+
+template <class F>
+__device__ __forceinline__ void cell_corners(const CellFoot &f, F body)
+{
+    // lower / upper value of an axis picked by a bit of the (uniform) corner number, as l ^ ((l ^ h) & mask): written
+    // as a conditional the compiler turns the pair into a two-element array in scratch memory indexed by the bit
+    const unsigned x0 = f.l0 ^ f.h0, x1 = f.l1 ^ f.h1, x2 = f.l2 ^ f.h2;
+    const unsigned y0 = __float_as_uint(f.wl0) ^ __float_as_uint(f.wh0), y1 = __float_as_uint(f.wl1) ^ __float_as_uint(f.wh1),
+                   y2 = __float_as_uint(f.wl2) ^ __float_as_uint(f.wh2);
+#pragma unroll 1
+    for (int cc = 0; cc < 8; ++cc) {
+        const unsigned m0 = 0u - ((unsigned)(cc >> 2) & 1u), m1 = 0u - ((unsigned)(cc >> 1) & 1u), m2 = 0u - ((unsigned)cc & 1u);
+        const unsigned c0 = f.l0 ^ (x0 & m0), c1 = f.l1 ^ (x1 & m1), c2 = f.l2 ^ (x2 & m2);
+        if (((c0 >> 2) | (c1 >> 2) | (c2 >> 3)) == 0u) {       // inside the 4 x 4 x 8 tile
+            // (w0 * w1) first, like the reference's product order (projection.py:319-323)
+            const float w0 = __uint_as_float(__float_as_uint(f.wl0) ^ (y0 & m0));
+            const float w1 = __uint_as_float(__float_as_uint(f.wl1) ^ (y1 & m1));
+            const float w2 = __uint_as_float(__float_as_uint(f.wl2) ^ (y2 & m2));
+            const float w01 = w0 * w1;
+            const float pw = w01 * w2;
+            body((int)((c0 << 5) | (c1 << 3) | c2), 1e-9f + pw);
+        }
+    }
+}
 
 template <int KIND, int OVM, bool STAMPS = false>     // OVM: float4s of the tile image per thread (ceil(32 C / 256))
 __global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
@@ -1411,7 +1460,7 @@ __global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-    constexpr int NT = CELLS_NT, TV = 1 << CELLS_SV;
+    constexpr int NT = CELLS_NT, TV = 1 << CELLS_SV, CEB = CELLS_EB;
     const int tid = threadIdx.x;
     const int C = P.C, G = P.G, CAP = P.cells_cap;
     const int m1 = (1 << P.s1) - 1;
@@ -1467,29 +1516,32 @@ __global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
     for (unsigned i = tid; i < n_el; i += NT) Du[i] = 0u;
     __syncthreads();
     if (tid < 64) {
+        // this tile, the next one (both published in LDS), the two after it (wave 0's registers), the work list
+        // entry of the one after those (load in flight) and one more ticket (atomic in flight)
         const int nb = gridDim.x, b = blockIdx.x;
-        const int t0 = resolve(b);
-        const int o0 = tile_range(t0);
-        if (tid == 0) misc[M_TILE] = t0;
-        if (tid <= 1) misc[M_OFF + tid] = o0;
-        nx_tile = resolve(b + nb);
+        const int t0 = resolve(b), t1 = resolve(b + nb);
+        const int o0 = tile_range(t0), o1 = tile_range(t1);
+        if (tid == 0) { misc[M_TILE] = t0; misc[M_NEXT] = t1; }
+        if (tid <= 1) { misc[M_OFF + tid] = o0; misc[M_OFFN + tid] = o1; }
+        nx_tile = resolve(b + 2 * nb);
         nx_off = tile_range(nx_tile);
-        rng_tile = resolve(b + 2 * nb);
+        rng_tile = resolve(b + 3 * nb);
         rng_off = tile_range(rng_tile);
-        act_pend = resolve(b + 3 * nb);
-        idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
-        idx_pend = __shfl(idx_pend, 0, 64);
+        int tk = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
+        tk = __shfl(tk, 0, 64);
+        act_pend = resolve(tk);
+        idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;     // consumed one tile later (lane 0)
     }
     __syncthreads();
     int tile = misc[M_TILE];
     if (tile < 0) return;
 
     // the first EB x NT records of a tile are fetched one tile ahead and stay in registers for all passes
-    uint4 pre[EB], nxt[EB];
-    uint32_t prex[EB], nxtx[EB];
-    auto prefetch_entries = [&](int ta, int tb, uint4 (&q)[EB], uint32_t (&qx)[EB]) {
+    uint4 pre[CEB], nxt[CEB];
+    uint32_t prex[CEB], nxtx[CEB];
+    auto prefetch_entries = [&](int ta, int tb, uint4 (&q)[CEB], uint32_t (&qx)[CEB]) {
 #pragma unroll
-        for (int j = 0; j < EB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
+        for (int j = 0; j < CEB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
             const int e = min(ta + tid + j * NT, tb - 1);
             q[j] = P.rec[e];
             qx[j] = KIND == 1 ? P.aux[e] : 0u;
@@ -1531,36 +1583,34 @@ __global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
         int o0, o1, o2;
         tile_origin(tile, o0, o1, o2);
         const int t_a = misc[M_OFF], t_b = misc[M_OFF + 1];
-        int tile_n = -1;
+        const int tile_n = misc[M_NEXT];
+        if (tile_n >= 0) prefetch_entries(misc[M_OFFN], misc[M_OFFN + 1], nxt, nxtx);   // the next tile's first records
         MF_STAMP(0)
-        // the tile's old rows: in flight during every pass, consumed by the final one
-        v4f oldv[OVM];
-#pragma unroll
-        for (int j = 0; j < OVM; ++j) {                    // unconditional: an element outside the map reads element 0
-            size_t g4;
-            const bool in = elem_index(tile, tid + j * NT, g4);
-            oldv[j] = map4[in ? g4 : 0];
-        }
         // records [ea, eb) of the tile, EB x NT at a time, batches aligned to the tile's first record so that the
         // first batch is always the register copy
         auto for_records = [&](int ea, int eb, auto body) {
-            const int bb0 = t_a + (ea - t_a) / (NT * EB) * (NT * EB);
-            for (int bb = bb0; bb < eb; bb += NT * EB) {
-                uint4 r[EB];
-                uint32_t x[EB];
-                if (bb == t_a) {
+            // (two separate code paths: a select between the register copy and a global load per batch makes the
+            // compiler keep the register copy in scratch memory and read both through flat loads)
+            if (ea < t_a + NT * CEB) {
 #pragma unroll
-                    for (int j = 0; j < EB; ++j) { r[j] = pre[j]; x[j] = prex[j]; }
-                } else {
+                for (int j = 0; j < CEB; ++j) {
+                    const int e = t_a + tid + j * NT;
+                    if (e >= ea && e < eb) body(pre[j], prex[j]);
+                }
+            }
+            int bb = t_a + (ea - t_a) / (NT * CEB) * (NT * CEB);
+            if (bb == t_a) bb += NT * CEB;
+            for (; bb < eb; bb += NT * CEB) {
+                uint4 r[CEB];
+                uint32_t x[CEB];
 #pragma unroll
-                    for (int j = 0; j < EB; ++j) {
-                        const int e = min(bb + tid + j * NT, eb - 1);
-                        r[j] = P.rec[e];
-                        x[j] = KIND == 1 ? P.aux[e] : 0u;
-                    }
+                for (int j = 0; j < CEB; ++j) {
+                    const int e = min(bb + tid + j * NT, eb - 1);
+                    r[j] = P.rec[e];
+                    x[j] = KIND == 1 ? P.aux[e] : 0u;
                 }
 #pragma unroll
-                for (int j = 0; j < EB; ++j) {
+                for (int j = 0; j < CEB; ++j) {
                     const int e = bb + tid + j * NT;
                     if (e >= ea && e < eb) body(r[j], x[j]);
                 }
@@ -1582,7 +1632,7 @@ __global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
                 // ---- mask pass: which frames of the window touch which voxel
                 for_records(ea, eb, [&](const uint4 &r, uint32_t) {
                     const unsigned long long bit = 1ull << (rec_group(r) - F);
-                    for_corners(P, r, o0, o1, o2, [&](int v, float) { atomicOr(&mask[v], bit); });
+                    cell_corners(cell_foot(P, r, o0, o1, o2), [&](int v, float) { atomicOr(&mask[v], bit); });
                 });
                 barrier_keep_vm();
                 MF_STAMP(1)
@@ -1613,29 +1663,15 @@ __global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
                 for_records(ea, eb, [&](const uint4 &r, uint32_t) {
                     const int fl = rec_group(r) - F;
                     const unsigned long long below = (1ull << fl) - 1ull;
-                    for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                    cell_corners(cell_foot(P, r, o0, o1, o2), [&](int v, float w) {
                         const int ci = cbase[v] + __popcll(mask[v] & below);
                         atomicAdd(&cells[2 * ci], to_fixed(w, fx_c));
                         atomicAdd(&cells[2 * ci + 1], to_fixed(w * w, fx_c));
                     });
                 });
             }
-            if (first && tid < 64) {                        // advance the look-ups, once per tile
-                if (tid == 0) misc[M_NEXT] = nx_tile;
-                if (tid <= 1) misc[M_OFFN + tid] = nx_off;
-                nx_tile = rng_tile; nx_off = rng_off;
-                rng_tile = act_pend;
-                rng_off = tile_range(rng_tile);
-                act_pend = resolve(idx_pend);
-                idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
-                idx_pend = __shfl(idx_pend, 0, 64);
-            }
             barrier_keep_vm();
             MF_STAMP(3)
-            if (first) {
-                tile_n = misc[M_NEXT];
-                if (tile_n >= 0) prefetch_entries(misc[M_OFFN], misc[M_OFFN + 1], nxt, nxtx);   // the next tile's first records
-            }
             if (ea < eb) {
                 // ---- pass 2: per voxel, cells from the last frame to the first: t_f = g_f * prod_{f' > f} a_f';
                 // prod a over the window multiplies what the earlier windows left
@@ -1668,7 +1704,7 @@ __global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
                     if (KIND == 1 && x >= (uint32_t)C) return;
                     const int fl = rec_group(r) - F;
                     const unsigned long long below = (1ull << fl) - 1ull;
-                    for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                    cell_corners(cell_foot(P, r, o0, o1, o2), [&](int v, float w) {
                         const int ci = cbase[v] + __popcll(mask[v] & below);
                         const float term = (w * w) * klow(cells, 2 * ci);
                         unsigned m = (unsigned)(term * du_scale);
@@ -1690,31 +1726,52 @@ __global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
             if (F < G) barrier_keep_vm();                   // the next window's mask pass ORs into cleared masks
         }
         // ---- the tile's rows go out: old * prod a + D (every row whole: an untouched voxel is rewritten with the
-        // value it had), and the deltas are cleared
+        // value it had), and the deltas are cleared.  The old rows are loaded here, all of a thread's loads in flight
+        // at once (held across the passes they cost 42 registers: values + addresses); the other workgroups of the CU
+        // compute meanwhile.
+        v4f oldv[OVM];
+        size_t g4s[OVM];
+        bool ins[OVM];
+#pragma unroll
+        for (int j = 0; j < OVM; ++j) {                    // unconditional: an element outside the map reads element 0
+            ins[j] = elem_index(tile, tid + j * NT, g4s[j]);
+            oldv[j] = map4[ins[j] ? g4s[j] : 0];
+        }
 #pragma unroll
         for (int j = 0; j < OVM; ++j) {
-            size_t g4;
-            const unsigned q = tid + j * NT;
-            if (elem_index(tile, q, g4)) {
-                const unsigned i = q << 2;
+            const unsigned i = (unsigned)(tid + j * NT) << 2;
+            if (ins[j]) {
                 unsigned *d = Du + i;
-                v4f o;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned v = div_magic(i + k, P.magicC);
-                    o[k] = oldv[j][k] * atot[v] + (float)d[k] * du_inv;
-                    d[k] = 0u;
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned v = div_magic(i + q, P.magicC);
+                    oldv[j][q] = oldv[j][q] * atot[v] + (float)d[q] * du_inv;
+                    d[q] = 0u;
                 }
-                map4[g4] = o;
             }
         }
+        // Every load of this wave has landed (the rows were just used): the look-ups issued one tile ago cost no
+        // wait of their own here (vmcnt retires in order), and the new ones have a whole tile to come back.
+        if (tid < 64) {
+            if (tid <= 1) misc[M_OFF + tid] = misc[M_OFFN + tid];
+            if (tid == 0) misc[M_NEXT] = nx_tile;
+            if (tid <= 1) misc[M_OFFN + tid] = nx_off;
+            nx_tile = rng_tile; nx_off = rng_off;
+            rng_tile = act_pend;
+            rng_off = tile_range(rng_tile);
+            const int tk = __shfl(idx_pend, 0, 64);
+            act_pend = resolve(tk);
+            idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < OVM; ++j)
+            if (ins[j]) map4[g4s[j]] = oldv[j];
         MF_STAMP(6)
         if (tile_n < 0) break;
         tile = tile_n;
 #pragma unroll
-        for (int j = 0; j < EB; ++j) { pre[j] = nxt[j]; prex[j] = nxtx[j]; }
-        if (tid <= 1) misc[M_OFF + tid] = misc[M_OFFN + tid];
-        barrier_keep_vm();                                   // rows read, deltas / cells / masks clear, record range in place
+        for (int j = 0; j < CEB; ++j) { pre[j] = nxt[j]; prex[j] = nxtx[j]; }
+        barrier_keep_vm();                                   // rows read, deltas / cells / masks clear, look-up words in place
     }
     if (STAMPS && tid == 0) {
         unsigned long long tot = 0;

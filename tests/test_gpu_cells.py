@@ -40,7 +40,7 @@ def run_both(lay, ref, fr, sl, kind, C):
     batch = dict(position=fr["position"][sl], yaw=fr["yaw"][sl], elevation=fr["elevation"][sl], depth=fr["depth"][sl])
     if kind == "label":
         batch["semantic"] = fr["semantic"][sl]
-    lay.update_batch(batch, sequential=True, validate=False)
+    lay.update_batch(batch, sequential=True, **({"validate": False} if kind == "label" else {}))
     H, W = fr["depth"].shape[1:3]
     for t in range(sl.start, sl.stop):
         if kind == "label":
