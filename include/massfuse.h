@@ -162,9 +162,10 @@ MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float in
  * applies a staged workspace to the map.  Staging batch k+1 on a second stream while batch k is
  * being committed overlaps the two (the tile kernels leave half of the CUs' wave slots free);
  * commits must stay in order on one stream, each workspace is owned by its batch from stage to
- * the end of commit, and both calls take the same grid / frames / mode arguments. */
-MF_API int mf_fuse_frames_stage(const mf_grid *grid, const mf_frames *frames, int32_t mode,
-                         void *workspace, size_t workspace_bytes, void *stream);
+ * the end of commit, and both calls take the same grid / frames / weight / mode arguments (the
+ * blend weight decides with the feature kind how the points are bucketed). */
+MF_API int mf_fuse_frames_stage(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
+                         int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
 MF_API int mf_fuse_frames_commit(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
                           int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -67,7 +67,7 @@ SIGNATURES = {
     "mf_fuse_workspace_bytes": (c_size_t, [ctypes.POINTER(MfGrid), c_int64, c_int32]),
     "mf_fuse_frames": (ctypes.c_int, [ctypes.POINTER(MfGrid), ctypes.POINTER(MfFrames), c_float, c_int32,
                                       c_void_p, c_size_t, c_void_p]),
-    "mf_fuse_frames_stage": (ctypes.c_int, [ctypes.POINTER(MfGrid), ctypes.POINTER(MfFrames), c_int32,
+    "mf_fuse_frames_stage": (ctypes.c_int, [ctypes.POINTER(MfGrid), ctypes.POINTER(MfFrames), c_float, c_int32,
                                             c_void_p, c_size_t, c_void_p]),
     "mf_fuse_frames_commit": (ctypes.c_int, [ctypes.POINTER(MfGrid), ctypes.POINTER(MfFrames), c_float, c_int32,
                                              c_void_p, c_size_t, c_void_p]),

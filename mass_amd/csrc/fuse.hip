@@ -75,6 +75,7 @@ struct FuseParams {
     int nt0, nt1, nt2, n_tiles, n_keys;
     int gc;                    // frames per chunk in the tile kernel
     int vec4;                  // final pass may use 16-byte accesses
+    int meta;                  // records in the tile-local "meta" format (all-integer tile kernels), no aux words
     unsigned magicC;           // ceil(2^32 / C) (0 when C == 1)
     // workspace
     int *cursor;               // [n_keys + 1]
@@ -97,8 +98,8 @@ struct TileParams {
     int nt1, nt2, n_tiles;
     unsigned magicC;
     int gc, vec4, fx_shift;
+    int meta;                  // records are in the meta format (see make_meta_record)
     int cells_cap;             // fuse_cells_kernel: (voxel, frame) cells that fit its LDS
-    int mode_force;            // >= 0: the tile kernel with this mode number runs whatever tile_list_kernel chose (commit-time override)
     const int *cursor;
     int *ticket;
     int *ctr;                  // this kernel's work counter (one word of `ticket` per tile kernel)
@@ -235,6 +236,89 @@ __device__ __forceinline__ uint4 make_record(const Point &pt)
     return r;
 }
 
+// ----------------------------------------------------------------------------
+// tile-local records ("meta" format) of the all-integer tile kernels
+// ----------------------------------------------------------------------------
+// A record is written per (point, tile) pair anyway, so for the calls that go to fuse_dense_kernel /
+// fuse_cells_kernel (sequential or merged frames of class ids / ones, front end 0) scatter_kernel stores what the
+// tile kernels would otherwise derive again in every pass, in the same 16 bytes and with no separate class-id word:
+//   x  bits  0..7   corner c = 4 ca + 2 cb + cd lies inside the tile (ca / cb / cd pick the upper corner of axis 0 / 1 / 2)
+//      bits  8..10  d0 d1 d2: upper minus lower voxel index per axis (0 where the footprint is clamped at the map border)
+//      bits 11..20  tile-local id of the all-lower corner + META_VOFF (it may lie one voxel before the tile)
+//      bits 21..28  class id (255 = outside [0, C), counts as an all-zero feature row), bits 29..30 frame bits 6..7
+//   y, z, w  the three ratios (in [0, 1]: sign and top exponent bit clear); their two top bits carry frame bits 0..5.
+constexpr int META_VOFF = 128;
+
+struct AxisLocal { int l, d; bool in_lo, in_hi; };
+__device__ __forceinline__ AxisLocal axis_local(const AxisFoot &a, int origin, int shift)
+{
+    AxisLocal x;
+    x.l = a.lo - origin;
+    x.d = a.hi - a.lo;
+    x.in_lo = ((unsigned)x.l >> shift) == 0u;
+    x.in_hi = ((unsigned)(a.hi - origin) >> shift) == 0u;
+    return x;
+}
+
+__device__ __forceinline__ uint4 make_meta_record(const Point &pt, const AxisFoot &a0, const AxisFoot &a1, const AxisFoot &a2,
+                                                  int o0, int o1, int o2, int s0, int s1, int s2, uint32_t label)
+{
+    const AxisLocal x0 = axis_local(a0, o0, s0), x1 = axis_local(a1, o1, s1), x2 = axis_local(a2, o2, s2);
+    const uint32_t in8 = ((x0.in_lo ? 0x0fu : 0u) | (x0.in_hi ? 0xf0u : 0u)) & ((x1.in_lo ? 0x33u : 0u) | (x1.in_hi ? 0xccu : 0u)) &
+                         ((x2.in_lo ? 0x55u : 0u) | (x2.in_hi ? 0xaau : 0u));
+    const int v000 = x0.l * (1 << (s1 + s2)) + x1.l * (1 << s2) + x2.l;
+    const uint32_t g = (uint32_t)pt.group;
+    uint4 r;
+    r.x = in8 | ((uint32_t)x0.d << 8) | ((uint32_t)x1.d << 9) | ((uint32_t)x2.d << 10) | ((uint32_t)(v000 + META_VOFF) << 11) |
+          ((label > 255u ? 255u : label) << 21) | (((g >> 6) & 3u) << 29);
+    r.y = __float_as_uint(pt.r0) | ((g & 3u) << 30);
+    r.z = __float_as_uint(pt.r1) | (((g >> 2) & 3u) << 30);
+    r.w = __float_as_uint(pt.r2) | (((g >> 4) & 3u) << 30);
+    return r;
+}
+
+__device__ __forceinline__ int meta_frame(const uint4 &r)
+{
+    return (int)((r.y >> 30) | ((r.z >> 30) << 2) | ((r.w >> 30) << 4) | (((r.x >> 29) & 3u) << 6));
+}
+__device__ __forceinline__ uint32_t meta_label(const uint4 &r) { return (r.x >> 21) & 255u; }
+
+// What a pass needs of a meta record: tile-local ids and weights of the eight corners (static register picks once
+// the corner loop is unrolled), the inside mask.
+template <int S1, int S2>
+struct MetaCorners {
+    int v[8];
+    float w[8];
+    uint32_t in8;
+    __device__ __forceinline__ explicit MetaCorners(const uint4 &r)
+    {
+        in8 = r.x & 255u;
+        const int v000 = (int)((r.x >> 11) & 1023u) - META_VOFF;
+        const int e0 = (int)((r.x >> 8) & 1u) << (S1 + S2), e1 = (int)((r.x >> 9) & 1u) << S2, e2 = (int)((r.x >> 10) & 1u);
+        v[0] = v000; v[1] = v000 + e2; v[2] = v000 + e1; v[3] = v[2] + e2;
+        v[4] = v000 + e0; v[5] = v[4] + e2; v[6] = v[4] + e1; v[7] = v[6] + e2;
+        const float r0 = __uint_as_float(r.y & 0x3fffffffu), r1 = __uint_as_float(r.z & 0x3fffffffu), r2 = __uint_as_float(r.w & 0x3fffffffu);
+        // per axis (projection.py:280-316): r < 0.5: (0.5 - r, r + 0.5), else (1.5 - r, r - 0.5)
+        const float l0 = (r0 < 0.5f ? 0.5f : 1.5f) - r0, h0 = r0 + (r0 < 0.5f ? 0.5f : -0.5f);
+        const float l1 = (r1 < 0.5f ? 0.5f : 1.5f) - r1, h1 = r1 + (r1 < 0.5f ? 0.5f : -0.5f);
+        const float l2 = (r2 < 0.5f ? 0.5f : 1.5f) - r2, h2 = r2 + (r2 < 0.5f ? 0.5f : -0.5f);
+        // (w0 * w1) * w2 + 1e-9, the reference's product order (projection.py:319-323)
+        const float w00 = l0 * l1, w01 = l0 * h1, w10 = h0 * l1, w11 = h0 * h1;
+        w[0] = 1e-9f + w00 * l2; w[1] = 1e-9f + w00 * h2; w[2] = 1e-9f + w01 * l2; w[3] = 1e-9f + w01 * h2;
+        w[4] = 1e-9f + w10 * l2; w[5] = 1e-9f + w10 * h2; w[6] = 1e-9f + w11 * l2; w[7] = 1e-9f + w11 * h2;
+    }
+};
+
+// body(cc, v, w) for the corners of a meta record that lie inside the tile
+template <int S1, int S2, class F>
+__device__ __forceinline__ void meta_corners_idx(const uint4 &r, F body)
+{
+    const MetaCorners<S1, S2> m(r);
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc)
+        if (m.in8 & (1u << cc)) body(cc, m.v[cc], m.w[cc]);
+}
+
 template <int FRONT>
 __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
 {
@@ -312,10 +396,24 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
         if (hkey[s] != EMPTY) hcnt[s] = atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
     __syncthreads();
     if (n > 0) {
-        for (int i = 0; i < n; ++i) {
-            const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
-            P.rec[pos] = r;
-            if (P.feat_kind != MF_FEAT_ONES) P.aux[pos] = aux;
+        if (P.meta) {
+            // tile-local records for the all-integer tile kernels: same enumeration of the <= 8 tiles as point_keys
+            const AxisFoot a0 = axis_foot(pt.k0, pt.r0, P.size0), a1 = axis_foot(pt.k1, pt.r1, P.size1), a2 = axis_foot(pt.k2, pt.r2, P.size2);
+            const int t0[2] = {a0.lo >> P.s0, a0.hi >> P.s0}, t1[2] = {a1.lo >> P.s1, a1.hi >> P.s1}, t2[2] = {a2.lo >> P.s2, a2.hi >> P.s2};
+            const int m0 = t0[0] != t0[1] ? 2 : 1, m1 = t1[0] != t1[1] ? 2 : 1, m2 = t2[0] != t2[1] ? 2 : 1;
+            int i = 0;
+            for (int a = 0; a < m0; ++a)
+                for (int b = 0; b < m1; ++b)
+                    for (int c = 0; c < m2; ++c, ++i) {
+                        const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
+                        P.rec[pos] = make_meta_record(pt, a0, a1, a2, t0[a] << P.s0, t1[b] << P.s1, t2[c] << P.s2, P.s0, P.s1, P.s2, aux);
+                    }
+        } else {
+            for (int i = 0; i < n; ++i) {
+                const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
+                P.rec[pos] = r;
+                if (P.feat_kind != MF_FEAT_ONES) P.aux[pos] = aux;
+            }
         }
     }
 }
@@ -422,9 +520,10 @@ __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ 
         // voxel and frame or more is a real scene (a batch of unrelated frames has 0.03): the all-integer
         // tile kernel takes it when the call was bucketed on its tiles (dense_tv = their voxel count, else 0).
         const long long total = cursor[n_tiles * G], half = (long long)ticket[SPLIT_NONEMPTY] * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
-        // bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is, bits 22 / 23: forced (dev / tests)
+        // bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is, bits 22 / 23: forced (dev / tests),
+        // bit 24: the records are tile-local (meta format): only these two kernels read them
         const bool dense_ok = dense_tv & (1 << 20), cells_ok = dense_tv & (1 << 21);
-        const bool dense = dense_ok && !(dense_tv & (1 << 23)) && (total >= half || (dense_tv & (1 << 22)));
+        const bool dense = dense_ok && !(cells_ok && (dense_tv & (1 << 23))) && (total >= half || (dense_tv & (1 << 22)) || ((dense_tv & (1 << 24)) && !cells_ok));
         ticket[MODE_SLOT] = dense ? MODE_DENSE : cells_ok ? MODE_CELLS : MODE_TILES;
         ticket[HINT_SLOT] = (int)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
         ticket[HINT_SLOT + 1] = (int)(half > 0x7fffffffLL ? 0x7fffffffLL : half);
@@ -528,7 +627,7 @@ __device__ __forceinline__ void for_corners(const TileParams &P, const uint4 &r,
 
 // Dev-only phase accounting (MF_STAMPS=1): cycles of workgroup-thread 0 between
 // the barriers of the tile kernel, summed over all workgroups.
-__device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_stamps[16];
 #define MF_STAMP(i)                                                                   \
     if (STAMPS && tid == 0) {                                                         \
         const unsigned long long _t = __builtin_amdgcn_s_memtime();                   \
@@ -672,7 +771,7 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
     // wait (the old-map preload): nothing else is outstanding there, so reading the results of the
     // loads issued one tile earlier costs no wait of its own (vmcnt retires in order: waiting for an
     // old load at any other point would also wait for every younger load and store of the wave).
-    if ((P.mode_force >= 0 ? P.mode_force : P.ticket[MODE_SLOT]) != MODE_TILES) return;   // another tile kernel takes the call (uniform)
+    if (P.ticket[MODE_SLOT] != MODE_TILES) return;                               // another tile kernel takes the call (uniform)
     {
         int listed = 0;
 #pragma unroll
@@ -1053,7 +1152,8 @@ constexpr int DENSE_SV = 7;               // 4 x 4 x 8 tiles
 constexpr int DENSE_FX = 40;              // fraction bits of the deltas
 constexpr int DENSE_MAX_CHUNKS = 32;
 
-template <int KIND, int MAXT, bool STAMPS = false>
+// META: the records are in the tile-local meta format (sequential frames; class id and frame in the record, no aux words)
+template <int KIND, int MAXT, bool META, bool STAMPS = false>
 __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      // <= 128 VGPRs: two workgroups of 512 fit a CU when gc is small
 {
     extern __shared__ float smem[];
@@ -1078,7 +1178,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
     const float di_inv = __uint_as_float((unsigned)(127 - DENSE_FX) << 23);    // 2^-DENSE_FX
 
-    if ((P.mode_force >= 0 ? P.mode_force : P.ticket[MODE_SLOT]) != MODE_DENSE) return;   // another tile kernel takes the call (uniform)
+    if (P.ticket[MODE_SLOT] != MODE_DENSE) return;                             // another tile kernel takes the call (uniform)
     {
         int listed = 0;
 #pragma unroll
@@ -1138,7 +1238,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
         for (int j = 0; j < EB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
             const int e = min(ta + tid + j * NT, tb - 1);
             q[j] = P.rec[e];
-            qx[j] = KIND == 1 ? P.aux[e] : 0u;
+            qx[j] = (KIND == 1 && !META) ? P.aux[e] : 0u;
         }
     };
     auto tile_origin = [&](int t, int &o0, int &o1, int &o2) {
@@ -1181,12 +1281,14 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
 
             // ---- pass 1: W, S2 of every (voxel, frame) cell of the chunk
             auto p1_record = [&](const uint4 &r) {
-                const int f = rec_group(r) - f_base;
+                const int f = (META ? meta_frame(r) : rec_group(r)) - f_base;
                 unsigned long long *cell = A + (size_t)f * TVP * 2;
-                for_corners(P, r, o0, o1, o2, [&](int v, float w) {
+                auto add = [&](int, int v, float w) {
                     atomicAdd(&cell[2 * v], to_fixed(w, fx_c));
                     atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
-                });
+                };
+                if (META) meta_corners_idx<2, 3>(r, add);
+                else for_corners_idx(P, r, o0, o1, o2, add);
             };
             // A small tile (all its records fit the registers fetched a tile ahead) is taken from there, in
             // straight-line code.  A big tile is dealt in SEGMENTS: thread t walks records [t * S, (t + 1) * S) of
@@ -1288,12 +1390,13 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
             // read together (a corner outside the tile reads that of one inside), then integer atomics
             {
                 auto p3_record = [&](const uint4 &r, uint32_t x) {
-                    const unsigned long long *cell = A + (size_t)(rec_group(r) - f_base) * TVP * 2;
+                    const unsigned long long *cell = A + (size_t)((META ? meta_frame(r) : rec_group(r)) - f_base) * TVP * 2;
                     int vi[8];
                     float qv[8];
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
-                    for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+                    if (META) meta_corners_idx<2, 3>(r, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+                    else for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
                     int vf = 0;
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
@@ -1312,7 +1415,8 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
 #pragma unroll
                     for (int j = 0; j < EB; ++j) {
                         const int e = t_s + tid + j * NT;
-                        if (e >= ea && e < eb && (KIND == 0 || prex[j] < (uint32_t)C)) p3_record(pre[j], prex[j]);
+                        const uint32_t x = META ? meta_label(pre[j]) : prex[j];
+                        if (e >= ea && e < eb && (KIND == 0 || x < (uint32_t)C)) p3_record(pre[j], x);
                     }
                 } else {
                     for (int e = my0; e < my1; e += EB) {
@@ -1322,7 +1426,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
                         for (int j = 0; j < EB; ++j) {
                             const int q = min(e + j, my1 - 1);
                             r[j] = P.rec[q];
-                            x[j] = KIND == 1 ? P.aux[q] : 0u;
+                            x[j] = KIND != 1 ? 0u : META ? meta_label(r[j]) : P.aux[q];
                         }
 #pragma unroll
                         for (int j = 0; j < EB; ++j)
@@ -1386,397 +1490,403 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
 //   scan    cell index of (voxel v, frame f) = cellbase[v] + popcount(mask[v] & bits below f): the cells that
 //           exist are numbered densely, voxel-major, frames ascending inside a voxel;
 //   pass 1  W, S2 of every cell as 64-bit fixed-point integer atomics (exact, order independent);
-//   pass 2  one thread per voxel walks its cells from the last frame to the first (SUFFIX form of the unrolled
-//           blend, like fuse_dense_kernel):  m_n = (prod_f a_f) m_0 + sum_f t_f U_f,  t_f = g_f prod_{f' > f} a_f';
+//   pass 2  per cell g = iw / W and a = 1 - iw S2 / W (all threads), then one thread per voxel walks its cells
+//           from the last frame to the first (SUFFIX form of the unrolled blend, like fuse_dense_kernel):
+//           m_n = (prod_f a_f) m_0 + sum_f t_f U_f,  t_f = g_f prod_{f' > f} a_f';
 //   pass 3  D[v][class] += t_f w^2 as 32-bit fixed point (31 fraction bits: every term and every sum of terms of
 //           a (voxel, class) lies in [0, 1 + eps]; a positive term below one unit adds one unit so that
 //           "non-zero" survives): integer atomics that return nothing;
-//   final   rows out: old * prod a + D, the old values having been loaded into registers at the start of the
-//           tile (they never enter LDS).
-// Seven barriers per tile, every pass over all records of the tile at once; the LDS image is ~53 KB at C = 54
-// (deltas 27 KB + 1,500 cells), so three 256-thread workgroups share a CU and one's memory phases overlap the
-// others' compute.  A tile whose frames need more cells than fit (tiles next to the cameras) takes its frames
-// in several windows; a later window multiplies the deltas by its own prod a.  Calls of more than 64 frames
-// take 64 at a time the same way.  All sums are integers: results are run-to-run identical.
+//   final   rows out: old * prod a + D, the old rows loaded into registers (they never enter LDS).
+// Every pass takes all records of the tile at once; records are in the tile-local meta format (make_meta_record),
+// so a pass decodes one in ~40 instructions and reads the LDS words of all eight corners before it waits.
+// All global loads of a tile (the next tile's first records, the look-ups of the tiles after it, the old rows)
+// are issued together at the start of the final pass and waited for once: no pass has a load in flight, so the
+// compiler puts no vmcnt wait into them (it tracks the counter exactly only in straight-line code).
+// A tile whose frames need more cells than fit (tiles next to the cameras) keeps its masks and takes its frames
+// in several windows; a later window multiplies the deltas by its own prod a.  Calls of more than 64 frames take
+// 64 at a time the same way.  All sums are integers: results are run-to-run identical.
 // tile_list_kernel picks this kernel or fuse_dense_kernel from the call's density; both work on 4 x 4 x 8 tiles.
-constexpr int CELLS_SV = 7;               // 4 x 4 x 8 tiles
 constexpr int CELLS_FX = 31;              // fraction bits of the deltas
-constexpr int CELLS_NT = 256;
-#ifndef CELLS_EB_DEF
-#define CELLS_EB_DEF 2
+constexpr int CELLS_MISC = 32 + 64;       // look-up words + per-frame cell counts of a window search
+#ifndef CELLS_RB_DEF
+#define CELLS_RB_DEF 512
 #endif
-constexpr int CELLS_EB = CELLS_EB_DEF;    // records per thread fetched a tile ahead and kept in registers
-constexpr int CELLS_OVM = 8;              // float4s of the tile image a thread owns at most (C <= 64)
-constexpr int CELLS_MISC = 32;
+constexpr int CELLS_RB = CELLS_RB_DEF;    // records of a tile kept in LDS per 256 threads (its first ones, fetched a tile ahead)
 
-// The 8 corners of a record on a 4 x 4 x 8 tile, visited by a ROLLED loop: per-axis tile-local coordinates and
-// weights are computed once, a corner picks its three by the bits of its number (uniform selects).  The unrolled
-// visitor of fuse_tiles_kernel (for_corners_idx) keeps all eight corners' values live at once (~130 VGPRs in
-// this kernel's passes, with spills at three waves per SIMD); rolled, a pass needs ~40.
-struct CellFoot { unsigned l0, h0, l1, h1, l2, h2; float wl0, wh0, wl1, wh1, wl2, wh2; };
-
-__device__ __forceinline__ CellFoot cell_foot(const TileParams &P, const uint4 &r, int o0, int o1, int o2)
-{
-    const int k0 = r.x & 1023, k1 = (r.x >> 10) & 1023, k2 = (r.x >> 20) & 1023;
-    const unsigned rm = 0x3fffffffu;                // sequential frames: the two top bits of each word carry the frame
-    const AxisFoot a0 = axis_foot(k0, __uint_as_float(r.y & rm), P.size0);
-    const AxisFoot a1 = axis_foot(k1, __uint_as_float(r.z & rm), P.size1);
-    const AxisFoot a2 = axis_foot(k2, __uint_as_float(r.w & rm), P.size2);
-    CellFoot f;
-    f.l0 = (unsigned)(a0.lo - o0); f.h0 = (unsigned)(a0.hi - o0);
-    f.l1 = (unsigned)(a1.lo - o1); f.h1 = (unsigned)(a1.hi - o1);
-    f.l2 = (unsigned)(a2.lo - o2); f.h2 = (unsigned)(a2.hi - o2);
-    f.wl0 = a0.wlo; f.wh0 = a0.whi; f.wl1 = a1.wlo; f.wh1 = a1.whi; f.wl2 = a2.wlo; f.wh2 = a2.whi;
-    return f;
-}
-
-template <class F>
-__device__ __forceinline__ void cell_corners(const CellFoot &f, F body)
-{
-    // lower / upper value of an axis picked by a bit of the (uniform) corner number, as l ^ ((l ^ h) & mask): written
-    // as a conditional the compiler turns the pair into a two-element array in scratch memory indexed by the bit
-    const unsigned x0 = f.l0 ^ f.h0, x1 = f.l1 ^ f.h1, x2 = f.l2 ^ f.h2;
-    const unsigned y0 = __float_as_uint(f.wl0) ^ __float_as_uint(f.wh0), y1 = __float_as_uint(f.wl1) ^ __float_as_uint(f.wh1),
-                   y2 = __float_as_uint(f.wl2) ^ __float_as_uint(f.wh2);
-#pragma unroll 1
-    for (int cc = 0; cc < 8; ++cc) {
-        const unsigned m0 = 0u - ((unsigned)(cc >> 2) & 1u), m1 = 0u - ((unsigned)(cc >> 1) & 1u), m2 = 0u - ((unsigned)cc & 1u);
-        const unsigned c0 = f.l0 ^ (x0 & m0), c1 = f.l1 ^ (x1 & m1), c2 = f.l2 ^ (x2 & m2);
-        if (((c0 >> 2) | (c1 >> 2) | (c2 >> 3)) == 0u) {       // inside the 4 x 4 x 8 tile
-            // (w0 * w1) first, like the reference's product order (projection.py:319-323)
-            const float w0 = __uint_as_float(__float_as_uint(f.wl0) ^ (y0 & m0));
-            const float w1 = __uint_as_float(__float_as_uint(f.wl1) ^ (y1 & m1));
-            const float w2 = __uint_as_float(__float_as_uint(f.wl2) ^ (y2 & m2));
-            const float w01 = w0 * w1;
-            const float pw = w01 * w2;
-            body((int)((c0 << 5) | (c1 << 3) | c2), 1e-9f + pw);
-        }
-    }
-}
-
-template <int KIND, int OVM, bool STAMPS = false>     // OVM: float4s of the tile image per thread (ceil(32 C / 256))
-__global__ __launch_bounds__(CELLS_NT, 3) void fuse_cells_kernel(TileParams P)
+template <int KIND, int S0, int S1, int S2, int NT, int F4, bool STAMPS = false>   // F4: float4s per lane and tile row (ceil(C 2^S2 / 256))
+__global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_cells_kernel(TileParams P)
 {
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-    constexpr int NT = CELLS_NT, TV = 1 << CELLS_SV, CEB = CELLS_EB;
-    const int tid = threadIdx.x;
+    constexpr int SV = S0 + S1 + S2, TV = 1 << SV, NW = NT / 64, CEB = CELLS_RB / 256, RB = NT * CEB;
+    constexpr int N_ROWS = TV >> S2, RPW = (N_ROWS + NW - 1) / NW;          // tile rows, rows per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = P.C, G = P.G, CAP = P.cells_cap;
-    const int m1 = (1 << P.s1) - 1;
     const unsigned n_el = (unsigned)TV * (unsigned)C;
-    unsigned long long *cells = reinterpret_cast<unsigned long long *>(smem);  // [CAP + 1][2] W, S2; low word of W = t_f after pass 2
-    unsigned long long *mask = cells + (size_t)(CAP + 1) * 2;                   // [TV] frames of the window that touch the voxel
-    unsigned *Du = reinterpret_cast<unsigned *>(mask + TV);                     // [TV][C] deltas, units of 2^-CELLS_FX
-    float *atot = reinterpret_cast<float *>(Du + n_el);                         // [TV] prod a over the frames so far
-    int *cbase = reinterpret_cast<int *>(atot + TV);                            // [TV + 2] first cell of the voxel; [TV] = cells in use
-    int *misc = cbase + TV + 2;                                                 // look-up words (indices below)
-    constexpr int M_TILE = 0, M_NEXT = 1, M_FIT = 2, M_EA = 3, M_EB = 4, M_OFF = 6 /* [2] */, M_OFFN = 8 /* [2] */,
-                  M_CLS = 12 /* [TILE_CLASSES] */;
-    static_assert(M_CLS + TILE_CLASSES <= CELLS_MISC, "misc words");
+    // LDS: per voxel {mask (u64), cell base, prod a}, cells, deltas, look-up words
+    struct Vox { unsigned long long mask; int cbase; float atot; };
+    Vox *vox = reinterpret_cast<Vox *>(smem);                                        // [TV + 1] ([TV].cbase = cells in use)
+    unsigned long long *cells = reinterpret_cast<unsigned long long *>(vox + TV + 1);   // [CAP + 1][2] W, S2; then (g, a); then t_f
+    uint4 *recbuf = reinterpret_cast<uint4 *>(cells + (size_t)(CAP + 1) * 2);        // [RB] the tile's first records: thread t owns slots t + j NT
+    unsigned *Du = reinterpret_cast<unsigned *>(recbuf + RB);                        // [TV][C] deltas, units of 2^-CELLS_FX
+    int *misc = reinterpret_cast<int *>(Du + n_el);
+    constexpr int M_TILE = 0, M_NEXT = 1, M_FIT = 2, M_EA = 3 /* [2] */, M_OFF = 6 /* [2] */, M_OFFN = 8 /* [2] */,
+                  M_CLS = 12 /* [TILE_CLASSES] */, M_CNT = 32 /* [64] inclusive per-frame cell counts */;
+    static_assert(M_CLS + TILE_CLASSES <= 32, "misc words");
     const int fx_c = 182 - P.fx_shift;
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
     const float du_inv = __uint_as_float((unsigned)(127 - CELLS_FX) << 23);    // 2^-CELLS_FX
     const float du_scale = __uint_as_float((unsigned)(127 + CELLS_FX) << 23);  // 2^CELLS_FX
 
-    if ((P.mode_force >= 0 ? P.mode_force : P.ticket[MODE_SLOT]) != MODE_CELLS) return;   // another tile kernel takes the call (uniform)
+    if (P.ticket[MODE_SLOT] != MODE_CELLS) return;                             // fuse_dense_kernel takes the call (uniform)
     {
         int listed = 0;
 #pragma unroll
         for (int c = 0; c < TILE_CLASSES; ++c) listed += P.ticket[1 + c];
         if (listed == 0) return;
     }
-    auto resolve = [&](int idx) {          // work list position -> tile id, -1 past the end
-        int tile_id = -1;
+    // work list position -> tile id, -1 past the end: the class is found from the class sizes (LDS), then ONE load
+    // (a chain of conditional loads, one per class, makes the compiler wait for memory after each of them)
+    auto resolve = [&](int idx) {
+        int cls = -1, pos = 0, rest = idx;
 #pragma unroll
         for (int c = 0; c < TILE_CLASSES; ++c) {
             const int cc = misc[M_CLS + c];
-            if (tile_id < 0 && idx >= 0 && idx < cc) tile_id = P.active[c * P.n_tiles + idx];
-            idx -= cc;
+            if (cls < 0 && rest >= 0 && rest < cc) { cls = c; pos = rest; }
+            rest -= cc;
         }
-        return tile_id;
+        return cls >= 0 ? P.active[cls * P.n_tiles + pos] : -1;
     };
-    // first record of bucket k (after scatter_kernel cursor[k] is the END of bucket k)
+    // first record of bucket k (after scatter_kernel cursor[k] is the END of bucket k); k <= n_tiles * G = n_keys
+    // whenever the tile id comes from the work list and the frame is <= G, so cursor[k - 1] is inside the scanned array
     auto bucket_start = [&](int k) { return k > 0 ? P.cursor[k - 1] : 0; };
-    // lane 0: first record of tile t, lane 1: one past its last (wave 0 only; tile ids below n_tiles by construction
-    // of the work list, so k <= n_tiles * G = n_keys and cursor[k - 1] is inside the scanned array)
-    auto tile_range = [&](int t) {
+    auto tile_range = [&](int t) {         // lane 0: first record of tile t, lane 1: one past its last (wave 0)
         int o = 0;
         if (t >= 0 && tid <= 1) o = bucket_start((t + tid) * G);
         return o;
     };
-    // Look-ups of the tiles ahead (work list entry -> record range: dependent global round trips) are made by
-    // wave 0 and advanced once per tile; the first four list positions of a workgroup are dealt statically
-    // (b, b + n, b + 2n, b + 3n: the list is heaviest first), tickets start at 4n (tile_list_kernel).
-    int idx_pend = -1, act_pend = -1, rng_tile = -1, rng_off = 0, nx_tile = -1, nx_off = 0;
+    // Look-ups of the tiles ahead (ticket -> work list entry -> record range: dependent global round trips) are
+    // made by wave 0, one stage per tile, at the start of the final pass.
+    int tk_next = 0, tk_end = 0, act_pend = -1, rng_tile = -1, rng_off = 0, nx_tile = -1, nx_off = 0;
+    constexpr int TK_BATCH = 8;            // tickets drawn at a time: the returning atomic is a memory round trip that has to be waited for
     if (tid == 0)
 #pragma unroll
         for (int c = 0; c < TILE_CLASSES; ++c) misc[M_CLS + c] = P.ticket[1 + c];
-    for (int i = tid; i < (CAP + 1) * 2 + TV; i += NT) cells[i] = 0ull;          // cells and masks
+    for (int i = tid; i < (TV + 1) * 2 + (CAP + 1) * 2; i += NT) reinterpret_cast<unsigned long long *>(smem)[i] = 0ull;   // voxel words, cells
     for (unsigned i = tid; i < n_el; i += NT) Du[i] = 0u;
     __syncthreads();
     if (tid < 64) {
         // this tile, the next one (both published in LDS), the two after it (wave 0's registers), the work list
-        // entry of the one after those (load in flight) and one more ticket (atomic in flight)
-        const int nb = gridDim.x, b = blockIdx.x;
-        const int t0 = resolve(b), t1 = resolve(b + nb);
+        // entry of the one after those (load in flight) and one more ticket (atomic in flight).  Only the first
+        // item of a workgroup is dealt statically (list position b: the list is heaviest first, so every
+        // workgroup starts on one of the n heaviest tiles); everything else is drawn from the counter, which
+        // tile_list_kernel starts at n.  (Four static items per workgroup, as fuse_tiles_kernel deals them, hand
+        // some of the workgroups four of the few hundred tiles that hold a quarter of all records.)
+        const int b = blockIdx.x;
+        int tk = tid == 0 ? atomicAdd(P.ctr, TK_BATCH) : 0;    // a workgroup's list positions ascend, so "past the end" for
+        tk = __shfl(tk, 0, 64);                                 // one item implies it for all later ones
+        tk_next = tk + 4; tk_end = tk + TK_BATCH;
+        const int t0 = resolve(b), t1 = resolve(tk);
         const int o0 = tile_range(t0), o1 = tile_range(t1);
         if (tid == 0) { misc[M_TILE] = t0; misc[M_NEXT] = t1; }
         if (tid <= 1) { misc[M_OFF + tid] = o0; misc[M_OFFN + tid] = o1; }
-        nx_tile = resolve(b + 2 * nb);
+        nx_tile = resolve(tk + 1);
         nx_off = tile_range(nx_tile);
-        rng_tile = resolve(b + 3 * nb);
+        rng_tile = resolve(tk + 2);
         rng_off = tile_range(rng_tile);
-        int tk = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
-        tk = __shfl(tk, 0, 64);
-        act_pend = resolve(tk);
-        idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;     // consumed one tile later (lane 0)
+        act_pend = resolve(tk + 3);
     }
     __syncthreads();
-    int tile = misc[M_TILE];
+    int tile = __builtin_amdgcn_readfirstlane(misc[M_TILE]);
     if (tile < 0) return;
 
-    // the first EB x NT records of a tile are fetched one tile ahead and stay in registers for all passes
-    uint4 pre[CEB], nxt[CEB];
-    uint32_t prex[CEB], nxtx[CEB];
-    auto prefetch_entries = [&](int ta, int tb, uint4 (&q)[CEB], uint32_t (&qx)[CEB]) {
-#pragma unroll
-        for (int j = 0; j < CEB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
-            const int e = min(ta + tid + j * NT, tb - 1);
-            q[j] = P.rec[e];
-            qx[j] = KIND == 1 ? P.aux[e] : 0u;
-        }
+    // the first CEB x NT records of a tile are fetched one tile ahead and stay in registers for all passes
+    static_assert(CEB == 1 || CEB == 2, "one or two records per thread are fetched ahead");
+    uint4 pre0, pre1 = make_uint4(0u, 0u, 0u, 0u);      // (named registers: an array indexed in a lambda ends up in scratch memory)
+    auto prefetch_entries = [&](int ta, int tb) {       // unconditional (clamped) loads
+        pre0 = P.rec[min(ta + tid, tb - 1)];
+        if (CEB == 2) pre1 = P.rec[min(ta + tid + NT, tb - 1)];
     };
     auto tile_origin = [&](int t, int &o0, int &o1, int &o2) {
         const int tz = t % P.nt2, ty = (t / P.nt2) % P.nt1, tx = t / (P.nt2 * P.nt1);
-        o0 = tx << P.s0; o1 = ty << P.s1; o2 = tz << P.s2;
+        o0 = tx << S0; o1 = ty << S1; o2 = tz << S2;
     };
-    const unsigned n4 = n_el >> 2, row_len = (unsigned)C << P.s2;
     typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f *map4 = reinterpret_cast<v4f *>(P.map);
-    auto elem_index = [&](int t, unsigned q, size_t &g4) {  // float4 q of tile t -> float4 index in the map, false outside the map
-        int o0, o1, o2;
-        tile_origin(t, o0, o1, o2);
-        const unsigned i = q << 2;
-        const unsigned r = div_magic(i, P.magicC) >> P.s2;
-        const int l1 = r & m1, l0 = r >> P.s1;
-        g4 = ((((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * P.size2 + o2) * C + (i - r * row_len)) >> 2;
-        return q < n4 && o0 + l0 < P.size0 && o1 + l1 < P.size1;
-    };
-    // exclusive scan of the voxels' cell counts (wave 0, two voxels per lane)
-    auto scan_cells = [&]() {
+    // exclusive scan of the voxels' cell counts inside the frame window `wm` (wave 0, TV / 64 voxels per lane)
+    auto scan_cells = [&](unsigned long long wm) {
         if (tid < 64) {
-            const int n0 = __popcll(mask[2 * tid]), n1 = __popcll(mask[2 * tid + 1]);
-            int inc = n0 + n1;
+            constexpr int VPL = TV / 64;
+            int n[VPL], tot = 0;
+#pragma unroll
+            for (int q = 0; q < VPL; ++q) { n[q] = __popcll(vox[VPL * tid + q].mask & wm); tot += n[q]; }
+            int inc = tot;
             for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (tid >= o) inc += y; }
-            const int ex = inc - n0 - n1;
-            cbase[2 * tid] = ex;
-            cbase[2 * tid + 1] = ex + n0;
-            if (tid == 63) cbase[TV] = inc;
+            int ex = inc - tot;
+#pragma unroll
+            for (int q = 0; q < VPL; ++q) { vox[VPL * tid + q].cbase = ex; ex += n[q]; }
+            if (tid == 63) vox[TV].cbase = inc;
         }
     };
 
-    prefetch_entries(misc[M_OFF], misc[M_OFF + 1], pre, prex);
-    if (tid < TV) atot[tid] = 1.0f;
+    prefetch_entries(misc[M_OFF], misc[M_OFF + 1]);
+    const unsigned row_len = (unsigned)C << S2, row4 = row_len >> 2;
+    const size_t row_stride = (size_t)P.size2 * C;                       // floats between map rows (x + 1)
 
     while (true) {
         int o0, o1, o2;
         tile_origin(tile, o0, o1, o2);
-        const int t_a = misc[M_OFF], t_b = misc[M_OFF + 1];
-        const int tile_n = misc[M_NEXT];
-        if (tile_n >= 0) prefetch_entries(misc[M_OFFN], misc[M_OFFN + 1], nxt, nxtx);   // the next tile's first records
+        const int t_a = __builtin_amdgcn_readfirstlane(misc[M_OFF]), t_b = __builtin_amdgcn_readfirstlane(misc[M_OFF + 1]);
+        const int tile_n = __builtin_amdgcn_readfirstlane(misc[M_NEXT]);
+        const int tn_a = __builtin_amdgcn_readfirstlane(misc[M_OFFN]), tn_b = __builtin_amdgcn_readfirstlane(misc[M_OFFN + 1]);
+        const unsigned long long t_tile = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
         MF_STAMP(0)
-        // records [ea, eb) of the tile, EB x NT at a time, batches aligned to the tile's first record so that the
-        // first batch is always the register copy
+        // The tile's first RB records were fetched one tile ahead (registers); they go to this thread's own LDS slots
+        // (no other thread reads them: no barrier) so that every pass can take its records in ONE loop with ONE copy
+        // of the corner code: slot k < RB from LDS, the rest of a heavy tile from memory.  (Kept in registers, the
+        // copy needs a code path of its own per pass, and a select between the two makes the compiler spill it to
+        // scratch memory and read both through flat loads.)
+        recbuf[tid] = pre0;
+        if (CEB == 2) recbuf[tid + NT] = pre1;
         auto for_records = [&](int ea, int eb, auto body) {
-            // (two separate code paths: a select between the register copy and a global load per batch makes the
-            // compiler keep the register copy in scratch memory and read both through flat loads)
-            if (ea < t_a + NT * CEB) {
-#pragma unroll
-                for (int j = 0; j < CEB; ++j) {
-                    const int e = t_a + tid + j * NT;
-                    if (e >= ea && e < eb) body(pre[j], prex[j]);
-                }
-            }
-            int bb = t_a + (ea - t_a) / (NT * CEB) * (NT * CEB);
-            if (bb == t_a) bb += NT * CEB;
-            for (; bb < eb; bb += NT * CEB) {
-                uint4 r[CEB];
-                uint32_t x[CEB];
-#pragma unroll
-                for (int j = 0; j < CEB; ++j) {
-                    const int e = min(bb + tid + j * NT, eb - 1);
-                    r[j] = P.rec[e];
-                    x[j] = KIND == 1 ? P.aux[e] : 0u;
-                }
-#pragma unroll
-                for (int j = 0; j < CEB; ++j) {
-                    const int e = bb + tid + j * NT;
-                    if (e >= ea && e < eb) body(r[j], x[j]);
-                }
+            const int k1 = eb - t_a;
+#pragma unroll 1
+            for (int k = (ea - t_a) / NT * NT + tid; k < k1; k += NT) {       // k: index inside the tile; k < RB is wave-uniform
+                uint4 r;
+                // (the empty asm keeps the two loads apart: merged, they become one flat load through a selected pointer)
+                if (k < RB) { r = recbuf[k]; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
+                else { r = P.rec[t_a + k]; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
+                if (t_a + k >= ea) body(r);
             }
         };
+        // cell of every corner of a record (a corner outside the tile reads voxel 0: the reads of all eight corners
+        // are issued before the first is used, the atomics that follow are masked)
+        auto corner_cells = [&](const MetaCorners<S1, S2> &m, unsigned long long wbelow, int (&ci)[8]) {
+            unsigned long long mk[8];
+            int cb[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const Vox *x = vox + ((m.in8 >> c) & 1u ? m.v[c] : 0);
+                mk[c] = x->mask; cb[c] = x->cbase;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ci[c] = cb[c] + __popcll(mk[c] & wbelow);
+        };
 
-        int F = 0, win = 64;
         bool first = true;
-        while (F < G) {                                     // windows of at most 64 frames whose cells fit
-            int Fe = min(F + win, G);
-            int ea = t_a, eb = t_b;
-            if (!(F == 0 && Fe == G)) {                     // part of the tile's frames: look its record range up
-                if (tid <= 1) misc[M_EA + tid] = bucket_start(tile * G + (tid == 0 ? F : Fe));
+        for (int F = 0; F < G; F += 64) {                   // at most 64 frames share the voxels' masks
+            const int nf = min(64, G - F);
+            int sa = t_a, sb = t_b;
+            if (G > 64) {                                   // part of the tile's frames: look its record range up
+                if (tid <= 1) misc[M_EA + tid] = bucket_start(tile * G + (tid == 0 ? F : F + nf));
                 __syncthreads();
-                ea = misc[M_EA]; eb = misc[M_EA + 1];
+                sa = misc[M_EA]; sb = misc[M_EA + 1];
                 __syncthreads();
             }
-            if (ea < eb) {                                  // (uniform)
-                // ---- mask pass: which frames of the window touch which voxel
-                for_records(ea, eb, [&](const uint4 &r, uint32_t) {
-                    const unsigned long long bit = 1ull << (rec_group(r) - F);
-                    cell_corners(cell_foot(P, r, o0, o1, o2), [&](int v, float) { atomicOr(&mask[v], bit); });
-                });
-                barrier_keep_vm();
-                MF_STAMP(1)
-                scan_cells();
-                barrier_keep_vm();
-                if (cbase[TV] > CAP) {                      // (uniform) the window's cells do not fit: take the frames that do
+            if (sa >= sb) continue;                         // (uniform)
+            // ---- mask pass: which of these frames touch which voxel
+            for_records(sa, sb, [&](const uint4 &r) {
+                const MetaCorners<S1, S2> m(r);
+                const unsigned long long bit = 1ull << (meta_frame(r) - F);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if ((m.in8 >> c) & 1u) atomicOr(&vox[m.v[c]].mask, bit);
+            });
+            barrier_keep_vm();
+            MF_STAMP(1)
+            scan_cells(~0ull);
+            barrier_keep_vm();
+            const bool split = vox[TV].cbase > CAP;         // (uniform) the cells of these frames do not fit at once
+            if (split) {
+                // inclusive per-frame cell counts: a window is a run of frames whose cells fit
+                if (tid < 64) {
+                    int cnt = 0;
+                    for (int v = 0; v < TV; ++v) cnt += (int)((vox[v].mask >> tid) & 1ull);
+                    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(cnt, o, 64); if (tid >= o) cnt += y; }
+                    misc[M_CNT + tid] = cnt;
+                }
+                __syncthreads();
+            }
+            for (int f0 = 0; f0 < nf;) {                    // windows of frames [F + f0, F + f1)
+                int f1 = nf, ea = sa, eb = sb;
+                unsigned long long wm = ~0ull;
+                if (split) {
                     if (tid < 64) {
-                        int cnt = 0;
-                        for (int v = 0; v < TV; ++v) cnt += (int)((mask[v] >> tid) & 1ull);   // cells of frame F + tid
-                        int inc = cnt;
-                        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (tid >= o) inc += y; }
-                        const int fit = __popcll(__ballot(inc <= CAP));          // inc is non-decreasing over the lanes
-                        if (tid == 0) misc[M_FIT] = fit < 1 ? 1 : fit;           // a frame has at most TV <= CAP cells
+                        const int base = f0 > 0 ? misc[M_CNT + f0 - 1] : 0;
+                        const int fit = __popcll(__ballot(tid >= f0 && tid < nf && misc[M_CNT + tid] - base <= CAP));
+                        if (tid == 0) misc[M_FIT] = fit < 1 ? 1 : fit;       // a single frame has at most TV <= CAP cells
                     }
                     __syncthreads();
-                    const int n = misc[M_FIT];              // 1 <= n < 64 here
-                    Fe = F + n;
-                    win = n + (n >> 2) + 1;                 // the next window is sized by what fitted
-                    if (tid < TV) mask[tid] &= (1ull << n) - 1ull;
-                    if (tid == 0) misc[M_EB] = bucket_start(tile * G + Fe);
+                    f1 = f0 + misc[M_FIT];
+                    wm = (f1 >= 64 ? ~0ull : (1ull << f1) - 1ull) & ~((1ull << f0) - 1ull);
+                    if (tid <= 1) misc[M_EA + tid] = bucket_start(tile * G + F + (tid == 0 ? f0 : f1));
+                    scan_cells(wm);
                     __syncthreads();
-                    eb = misc[M_EB];
-                    scan_cells();
-                    __syncthreads();
+                    ea = misc[M_EA]; eb = misc[M_EA + 1];
                 }
                 MF_STAMP(2)
-                // ---- pass 1: W, S2 of every cell
-                for_records(ea, eb, [&](const uint4 &r, uint32_t) {
-                    const int fl = rec_group(r) - F;
-                    const unsigned long long below = (1ull << fl) - 1ull;
-                    cell_corners(cell_foot(P, r, o0, o1, o2), [&](int v, float w) {
-                        const int ci = cbase[v] + __popcll(mask[v] & below);
-                        atomicAdd(&cells[2 * ci], to_fixed(w, fx_c));
-                        atomicAdd(&cells[2 * ci + 1], to_fixed(w * w, fx_c));
+                if (ea < eb) {
+                    // ---- pass 1: W, S2 of every cell
+                    for_records(ea, eb, [&](const uint4 &r) {
+                        const MetaCorners<S1, S2> m(r);
+                        const int fl = meta_frame(r) - F;
+                        int ci[8];
+                        corner_cells(m, wm & ((1ull << fl) - 1ull), ci);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if ((m.in8 >> c) & 1u) {
+                                atomicAdd(&cells[2 * ci[c]], to_fixed(m.w[c], fx_c));
+                                atomicAdd(&cells[2 * ci[c] + 1], to_fixed(m.w[c] * m.w[c], fx_c));
+                            }
                     });
-                });
-            }
-            barrier_keep_vm();
-            MF_STAMP(3)
-            if (ea < eb) {
-                // ---- pass 2: per voxel, cells from the last frame to the first: t_f = g_f * prod_{f' > f} a_f';
-                // prod a over the window multiplies what the earlier windows left
-                if (tid < TV) {
-                    const int v = tid, cs = cbase[v], ce = cbase[v + 1];
-                    float run = 1.0f;
-                    for (int j = ce - 1; j >= cs; --j) {
-                        const float rW = __builtin_amdgcn_rcpf((float)cells[2 * j] * fx_inv);
-                        const float a = 1.0f - P.iw * (((float)cells[2 * j + 1] * fx_inv) * rW);
-                        reinterpret_cast<float *>(cells + 2 * j)[0] = P.iw * rW * run;
-                        run *= a;
+                    barrier_keep_vm();
+                    MF_STAMP(3)
+                    // ---- pass 2a: per cell g = iw / W, a = 1 - iw S2 / W (every thread takes cells)
+                    const int used = vox[TV].cbase;
+                    for (int i = tid; i < used; i += NT) {
+                        const float rW = __builtin_amdgcn_rcpf((float)cells[2 * i] * fx_inv);
+                        const float a = 1.0f - P.iw * (((float)cells[2 * i + 1] * fx_inv) * rW);
+                        float2 ga; ga.x = P.iw * rW; ga.y = a;
+                        *reinterpret_cast<float2 *>(cells + 2 * i) = ga;
                     }
-                    if (first) atot[v] = run;
-                    else if (ce > cs) {
-                        atot[v] *= run;
-                        for (int ch = 0; ch < C; ++ch) {
-                            const unsigned d = Du[v * C + ch];
-                            if (d != 0u) {
-                                unsigned nd = (unsigned)((double)d * (double)run);
-                                if (nd == 0u && run > 0.0f) nd = 1u;            // "non-zero" survives
-                                Du[v * C + ch] = nd;
+                    barrier_keep_vm();
+                    // ---- pass 2b: per voxel, cells from the last frame to the first: t_f = g_f prod_{f' > f} a_f';
+                    // prod a over the window multiplies what the earlier windows left
+                    if (tid < TV) {
+                        const int v = tid, cs = vox[v].cbase, ce = vox[v + 1].cbase;
+                        float run = 1.0f;
+                        for (int j = ce - 1; j >= cs; --j) {
+                            const float2 ga = *reinterpret_cast<const float2 *>(cells + 2 * j);
+                            reinterpret_cast<float *>(cells + 2 * j)[0] = ga.x * run;
+                            run *= ga.y;
+                        }
+                        if (first) vox[v].atot = run;
+                        else if (ce > cs) {
+                            vox[v].atot *= run;
+                            for (int ch = 0; ch < C; ++ch) {
+                                const unsigned d = Du[v * C + ch];
+                                if (d != 0u) {
+                                    unsigned nd = (unsigned)((double)d * (double)run);
+                                    if (nd == 0u && run > 0.0f) nd = 1u;            // "non-zero" survives
+                                    Du[v * C + ch] = nd;
+                                }
                             }
                         }
                     }
-                }
-                barrier_keep_vm();
-                MF_STAMP(4)
-                // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1)
-                for_records(ea, eb, [&](const uint4 &r, uint32_t x) {
-                    if (KIND == 1 && x >= (uint32_t)C) return;
-                    const int fl = rec_group(r) - F;
-                    const unsigned long long below = (1ull << fl) - 1ull;
-                    cell_corners(cell_foot(P, r, o0, o1, o2), [&](int v, float w) {
-                        const int ci = cbase[v] + __popcll(mask[v] & below);
-                        const float term = (w * w) * klow(cells, 2 * ci);
-                        unsigned m = (unsigned)(term * du_scale);
-                        if (m == 0u && term > 0.0f) m = 1u;
-                        if (m != 0u) atomicAdd(&Du[KIND == 0 ? v : v * C + (int)x], m);
+                    barrier_keep_vm();
+                    MF_STAMP(4)
+                    // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1)
+                    for_records(ea, eb, [&](const uint4 &r) {
+                        const uint32_t x = meta_label(r);
+                        if (KIND == 1 && x >= (uint32_t)C) return;
+                        const MetaCorners<S1, S2> m(r);
+                        const int fl = meta_frame(r) - F;
+                        int ci[8];
+                        corner_cells(m, wm & ((1ull << fl) - 1ull), ci);
+                        float t[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) t[c] = klow(cells, 2 * ((m.in8 >> c) & 1u ? ci[c] : 0));
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if ((m.in8 >> c) & 1u) {
+                                const float term = (m.w[c] * m.w[c]) * t[c];
+                                unsigned q = (unsigned)(term * du_scale);
+                                if (q == 0u && term > 0.0f) q = 1u;
+                                if (q != 0u) atomicAdd(&Du[KIND == 0 ? m.v[c] : m.v[c] * C + (int)x], q);
+                            }
                     });
-                });
-                barrier_keep_vm();
-                MF_STAMP(5)
-                // the window's cells and masks are cleared for the next window / tile
-                {
-                    const int used = cbase[TV];
-                    for (int i = tid; i < used * 2; i += NT) cells[i] = 0ull;
-                    if (tid < TV) mask[tid] = 0ull;
+                    barrier_keep_vm();
+                    MF_STAMP(5)
+                    for (int i = tid; i < used * 2; i += NT) cells[i] = 0ull;     // the window's cells
+                    first = false;
                 }
-            } else if (first && tid < TV) atot[tid] = 1.0f;
-            F = Fe;
-            first = false;
-            if (F < G) barrier_keep_vm();                   // the next window's mask pass ORs into cleared masks
-        }
-        // ---- the tile's rows go out: old * prod a + D (every row whole: an untouched voxel is rewritten with the
-        // value it had), and the deltas are cleared.  The old rows are loaded here, all of a thread's loads in flight
-        // at once (held across the passes they cost 42 registers: values + addresses); the other workgroups of the CU
-        // compute meanwhile.
-        v4f oldv[OVM];
-        size_t g4s[OVM];
-        bool ins[OVM];
-#pragma unroll
-        for (int j = 0; j < OVM; ++j) {                    // unconditional: an element outside the map reads element 0
-            ins[j] = elem_index(tile, tid + j * NT, g4s[j]);
-            oldv[j] = map4[ins[j] ? g4s[j] : 0];
-        }
-#pragma unroll
-        for (int j = 0; j < OVM; ++j) {
-            const unsigned i = (unsigned)(tid + j * NT) << 2;
-            if (ins[j]) {
-                unsigned *d = Du + i;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned v = div_magic(i + q, P.magicC);
-                    oldv[j][q] = oldv[j][q] * atot[v] + (float)d[q] * du_inv;
-                    d[q] = 0u;
-                }
+                f0 = f1;
+                if (f0 < nf) __syncthreads();               // the next window's scan writes the cell bases
             }
+            if (tid < TV) vox[tid].mask = 0ull;
+            if (F + 64 < G) __syncthreads();                // the next frames' mask pass ORs into cleared masks
         }
-        // Every load of this wave has landed (the rows were just used): the look-ups issued one tile ago cost no
-        // wait of their own here (vmcnt retires in order), and the new ones have a whole tile to come back.
+        // ---- final pass.  All global loads of the tile are issued here and waited for once.
         if (tid < 64) {
-            if (tid <= 1) misc[M_OFF + tid] = misc[M_OFFN + tid];
+            // look-ups: what was issued one tile ago has landed (it was covered by that tile's wait)
+            if (tid <= 1) misc[M_OFF + tid] = tn_a * (1 - tid) + tn_b * tid;
             if (tid == 0) misc[M_NEXT] = nx_tile;
             if (tid <= 1) misc[M_OFFN + tid] = nx_off;
             nx_tile = rng_tile; nx_off = rng_off;
             rng_tile = act_pend;
             rng_off = tile_range(rng_tile);
-            const int tk = __shfl(idx_pend, 0, 64);
-            act_pend = resolve(tk);
-            idx_pend = tid == 0 ? atomicAdd(P.ctr, 1) : 0;
+            if (tk_next == tk_end) {                            // (uniform) a new batch of tickets, once per TK_BATCH tiles
+                int tk = tid == 0 ? atomicAdd(P.ctr, TK_BATCH) : 0;
+                tk_next = __shfl(tk, 0, 64);
+                tk_end = tk_next + TK_BATCH;
+            }
+            act_pend = resolve(tk_next++);
+        }
+        if (tile_n >= 0) prefetch_entries(tn_a, tn_b);      // pass 3 is over: the register copy is free
+        // a wave takes whole tile rows (row, wave and the row's address are scalars); rows outside the map read row 0
+        v4f oldv[RPW][F4];
+        float *grow[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int r = wave + q * NW;
+            const int l1 = r & ((1 << S1) - 1), l0 = r >> S1;
+            const bool in = r < N_ROWS && o0 + l0 < P.size0 && o1 + l1 < P.size1;
+            grow[q] = in ? P.map + ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * row_stride + (size_t)o2 * C : nullptr;
+#pragma unroll
+            for (int f = 0; f < F4; ++f) {
+                const unsigned i4 = lane + 64 * f;
+                oldv[q][f] = reinterpret_cast<const v4f *>(grow[q] ? grow[q] : P.map)[i4 < row4 ? i4 : 0];
+            }
         }
 #pragma unroll
-        for (int j = 0; j < OVM; ++j)
-            if (ins[j]) map4[g4s[j]] = oldv[j];
+        for (int q = 0; q < RPW; ++q) {
+            const int r = wave + q * NW;
+#pragma unroll
+            for (int f = 0; f < F4; ++f) {
+                const unsigned i4 = lane + 64 * f;
+                if (grow[q] && i4 < row4) {
+                    const unsigned i = i4 << 2;                                   // float index inside the row
+                    const unsigned v0 = div_magic(i, P.magicC), rem = i - v0 * C;
+                    unsigned vv[4];
+                    vv[0] = v0;
+                    if (C >= 4) { vv[1] = v0 + (rem + 1 >= (unsigned)C); vv[2] = v0 + (rem + 2 >= (unsigned)C); vv[3] = v0 + (rem + 3 >= (unsigned)C); }
+                    else { vv[1] = div_magic(i + 1, P.magicC); vv[2] = div_magic(i + 2, P.magicC); vv[3] = div_magic(i + 3, P.magicC); }
+                    unsigned *d = Du + (unsigned)r * row_len + i;
+                    const uint4 dq = *reinterpret_cast<const uint4 *>(d);
+                    const unsigned dd[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        oldv[q][f][k] = oldv[q][f][k] * vox[(r << S2) + vv[k]].atot + (float)dd[k] * du_inv;
+                    *reinterpret_cast<uint4 *>(d) = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        }
+        if (STAMPS && tid == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); stamp_acc[7] += _t - t_last; t_last = _t; }
+#pragma unroll
+        for (int q = 0; q < RPW; ++q)
+#pragma unroll
+            for (int f = 0; f < F4; ++f) {
+                const unsigned i4 = lane + 64 * f;
+                if (grow[q] && i4 < row4) reinterpret_cast<v4f *>(grow[q])[i4] = oldv[q][f];
+            }
         MF_STAMP(6)
+        if (STAMPS && tid == 0) {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_tile;
+            const int nrec = t_b - t_a;
+            atomicMax(&g_stamps[8], dt);
+            const int cls = nrec > 2048 ? 0 : nrec > 512 ? 1 : 2;
+            atomicAdd(&g_stamps[9 + 2 * cls], dt);
+            atomicAdd(&g_stamps[10 + 2 * cls], 1ull);
+        }
         if (tile_n < 0) break;
         tile = tile_n;
-#pragma unroll
-        for (int j = 0; j < CEB; ++j) { pre[j] = nxt[j]; prex[j] = nxtx[j]; }
-        barrier_keep_vm();                                   // rows read, deltas / cells / masks clear, look-up words in place
+        barrier_keep_vm();                                   // rows combined, deltas / cells / masks clear, look-up words in place
     }
     if (STAMPS && tid == 0) {
         unsigned long long tot = 0;
-        for (int i = 0; i < 7; ++i) { atomicAdd(&g_stamps[i], stamp_acc[i]); tot += stamp_acc[i]; }
-        atomicMax(&g_stamps[7], tot);                   // the slowest workgroup
+        for (int i = 0; i < 8; ++i) { atomicAdd(&g_stamps[i], stamp_acc[i]); tot += stamp_acc[i]; }
+        atomicMax(&g_stamps[15], tot);                  // the slowest workgroup
     }
 }
 
@@ -2277,11 +2387,12 @@ static bool dense_shape_ok(const mf_grid *g, int G)
            ((size_t)g->channels << DENSE_SV) / 4 <= 4 * 512;
 }
 
-// fuse_cells_kernel: cap + 1 cells of 16 bytes, a mask per voxel, 4-byte deltas, prod a, cell bases, look-up words
+// fuse_cells_kernel: per voxel 16 bytes (mask, cell base, prod a), cap + 1 cells of 16 bytes, 4-byte deltas, look-up words
+constexpr int CELLS_SV = 7, CELLS_NT = 256;          // 4 x 4 x 8 tiles, 256 threads (the instantiation the host launches)
 static size_t cells_lds_bytes(int C, int cap)
 {
     const size_t TV = (size_t)1 << CELLS_SV;
-    return (size_t)(cap + 1) * 16 + TV * 8 + TV * C * 4 + TV * 4 + (TV + 2) * 4 + CELLS_MISC * 4;
+    return (TV + 1) * 16 + (size_t)(cap + 1) * 16 + (size_t)CELLS_RB * (CELLS_NT / 256) * 16 + TV * C * 4 + CELLS_MISC * 4;
 }
 
 // Workgroups of fuse_cells_kernel per CU and the cells each of them holds: as many workgroups as leave each at
@@ -2289,7 +2400,7 @@ static size_t cells_lds_bytes(int C, int cap)
 static bool cells_config(int C, int lds_per_cu, int &cap, int &per_cu)
 {
     static const int forced = env_int("MF_CELLS_PER_CU", 1, 8, 0);            // dev
-    if (((size_t)C << CELLS_SV) / 4 > (size_t)CELLS_OVM * CELLS_NT) return false;   // the tile image in a thread's float4 registers
+    if (C > 64) return false;                                                  // a tile row in two float4s per lane
     const size_t fixed = cells_lds_bytes(C, 0);
     for (per_cu = forced > 0 ? forced : 8; per_cu >= 1; --per_cu) {
         const size_t budget = ((size_t)lds_per_cu / per_cu) & ~(size_t)1023;   // LDS is handed out in blocks
@@ -2304,9 +2415,11 @@ static bool cells_config(int C, int lds_per_cu, int &cap, int &per_cu)
 // May a call of G sequential frames of class ids / ones onto this grid be bucketed on 4 x 4 x 8 tiles, for
 // fuse_dense_kernel / fuse_cells_kernel (tile_list_kernel picks one of them from the call's density)?  Decided
 // from the call's arguments alone, so a stage / commit pair and a repeated run agree.
-static bool int_tiles_ok(const mf_grid *g, int G, int feat_kind)
+static bool int_tiles_ok(const mf_grid *g, int G, int feat_kind, float iw)
 {
-    if (feat_kind == MF_FEAT_DENSE_F32 || !dense_shape_ok(g, G)) return false;
+    // (the all-integer kernels bound every term by 1, which needs 0 <= iw <= 1: any other blend weight, which the
+    // reference accepts, takes the float tile kernel)
+    if (feat_kind == MF_FEAT_DENSE_F32 || !(iw >= 0.0f && iw <= 1.0f) || !dense_shape_ok(g, G)) return false;
     return (uintptr_t)g->map % 16 == 0 && g->size2 % 8 == 0 &&
            (size_t)g->size0 * g->size1 * g->size2 * g->channels < ((size_t)1 << 34);
 }
@@ -2544,7 +2657,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     // tile shape: 4 x 4 x 8 for sequential frames of class ids / ones (the all-integer tile kernels), else by
     // the LDS budget of fuse_tiles_kernel; a function of the arguments only (a commit on its own agrees with its
     // staging call, a repeated run with itself)
-    const bool dense_tiles = FRONT == 0 && P.G >= 2 && int_tiles_ok(grid, P.G, P.feat_kind);
+    const bool dense_tiles = FRONT == 0 && P.G >= 2 && int_tiles_ok(grid, P.G, P.feat_kind, P.iw);
+    P.meta = dense_tiles ? 1 : 0;        // tile-local records: the all-integer kernels take every call bucketed on their tiles
     choose_tile(grid, P.G, dense_tiles, P.s0, P.s1, P.s2);
     Layout L;
     if (!make_layout(grid, P.n_points, P.G, P.s0, P.s1, P.s2, L, P.nt0, P.nt1, P.nt2))
@@ -2621,7 +2735,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     static const bool cells_on = env_int("MF_CELLS", 0, 1, 1) != 0;
     static const bool cells_forced = getenv("MF_CELLS_FORCE") != nullptr;
     int cells_cap = 0, cells_per_cu = 1;
-    const bool use_cells = cells_on && dense_tiles && sv == CELLS_SV && P.s2 == 3 && P.s0 == 2 && P.vec4 && P.G >= 2 &&
+    const bool use_cells = cells_on && dense_tiles && use_dense && sv == CELLS_SV && P.s2 == 3 && P.s0 == 2 && P.G >= 2 &&
                            cells_config(P.C, dev.lds_per_cu, cells_cap, cells_per_cu);
     int blocks_cells = dev.cus * cells_per_cu;
     if (blocks_cap > 0 && blocks_cells > blocks_cap) blocks_cells = blocks_cap;
@@ -2650,8 +2764,9 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
                        P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
                        (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks,
                        (use_dense || use_cells ? 1 << sv : 0) | (use_dense ? 1 << 20 : 0) | (use_cells ? 1 << 21 : 0) |
-                           (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0),
-                       4 * blocks_dense, 4 * blocks_cells);
+                           (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0) |
+                           (P.meta ? 1 << 24 : 0),
+                       4 * blocks_dense, blocks_cells);
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
@@ -2670,7 +2785,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     static const bool stamps = getenv("MF_STAMPS") != nullptr;
     if (stamps && nt > 256) kern = kind == 0 ? fuse_tiles_kernel<0, 1024, true> : kind == 1 ? fuse_tiles_kernel<1, 1024, true> : fuse_tiles_kernel<2, 1024, true>;
     if (stamps && nt <= 256 && nt > 64) kern = kind == 0 ? fuse_tiles_kernel<0, 256, true> : kind == 1 ? fuse_tiles_kernel<1, 256, true> : fuse_tiles_kernel<2, 256, true>;
-    if (stamps) { unsigned long long z[8] = {}; MF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z))); }
+    if (stamps) { unsigned long long z[16] = {}; MF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z))); }
     {
         // the dynamic-LDS limit of a kernel is raised once (per size): not a per-call cost
         static std::mutex mu;
@@ -2696,9 +2811,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
     T.ctr = P.ticket;
     T.cells_cap = cells_cap;
-    // the all-integer kernels bound every term by 1, which needs 0 <= iw <= 1; any other blend weight (the
-    // reference accepts it) is taken by fuse_tiles_kernel, on whatever tiles the call was bucketed
-    T.mode_force = (P.iw >= 0.0f && P.iw <= 1.0f) ? -1 : MODE_TILES;
+    T.meta = P.meta;
     // with ones features every tile of a single-group call goes to the single-pass kernel (tile_list_kernel,
     // min_mean = 0): nothing is listed for the tile kernel, whose launch is skipped
     if (!(single && P.feat_kind == MF_FEAT_ONES)) {
@@ -2707,10 +2820,17 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     }
     if (use_dense) {
         void (*dk)(TileParams);
-        if (dnt >= 1024) dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 1024, true> : fuse_dense_kernel<1, 1024, true>)
-                                     : (kind == 0 ? fuse_dense_kernel<0, 1024> : fuse_dense_kernel<1, 1024>);
-        else dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 512, true> : fuse_dense_kernel<1, 512, true>)
-                         : (kind == 0 ? fuse_dense_kernel<0, 512> : fuse_dense_kernel<1, 512>);
+        if (P.meta) {
+            if (dnt >= 1024) dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 1024, true, true> : fuse_dense_kernel<1, 1024, true, true>)
+                                         : (kind == 0 ? fuse_dense_kernel<0, 1024, true> : fuse_dense_kernel<1, 1024, true>);
+            else dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 512, true, true> : fuse_dense_kernel<1, 512, true, true>)
+                             : (kind == 0 ? fuse_dense_kernel<0, 512, true> : fuse_dense_kernel<1, 512, true>);
+        } else {
+            if (dnt >= 1024) dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 1024, false, true> : fuse_dense_kernel<1, 1024, false, true>)
+                                         : (kind == 0 ? fuse_dense_kernel<0, 1024, false> : fuse_dense_kernel<1, 1024, false>);
+            else dk = stamps ? (kind == 0 ? fuse_dense_kernel<0, 512, false, true> : fuse_dense_kernel<1, 512, false, true>)
+                             : (kind == 0 ? fuse_dense_kernel<0, 512, false> : fuse_dense_kernel<1, 512, false>);
+        }
         {
             static std::mutex mu3;
             static std::unordered_map<const void *, size_t> granted3;
@@ -2728,12 +2848,11 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         MF_LAUNCH_CHECK("fuse_dense_kernel");
     }
     if (use_cells) {
-        const int ovm = (int)((((size_t)P.C << CELLS_SV) / 4 + CELLS_NT - 1) / CELLS_NT);
+        const int f4 = (int)((((size_t)P.C << 3) / 4 + 63) / 64);          // float4s per lane and tile row
         void (*ck)(TileParams);
-        if (kind == 0) ck = stamps ? fuse_cells_kernel<0, 1, true> : fuse_cells_kernel<0, 1>;
-        else if (ovm <= 4) ck = stamps ? fuse_cells_kernel<1, 4, true> : fuse_cells_kernel<1, 4>;
-        else if (ovm <= 7) ck = stamps ? fuse_cells_kernel<1, 7, true> : fuse_cells_kernel<1, 7>;
-        else ck = stamps ? fuse_cells_kernel<1, 8, true> : fuse_cells_kernel<1, 8>;
+        if (kind == 0) ck = stamps ? fuse_cells_kernel<0, 2, 2, 3, CELLS_NT, 1, true> : fuse_cells_kernel<0, 2, 2, 3, CELLS_NT, 1>;
+        else if (f4 <= 1) ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 1, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 1>;
+        else ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 2, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 2>;
         const size_t clds = cells_lds_bytes(P.C, cells_cap);
         {
             static std::mutex mu4;
@@ -2783,7 +2902,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     prof_mark(5, st);
     if (g_profile && g_ev_ready && g_prof_calls < PROF_CALLS) ++g_prof_calls;
     if (stamps) {
-        unsigned long long z[8];
+        unsigned long long z[16];
         MF_HIP_CHECK(hipStreamSynchronize(st));
         MF_HIP_CHECK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_stamps), sizeof(z)));
         double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)z[i];
@@ -2791,9 +2910,13 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         fprintf(stderr, "[MF_STAMPS] blocks=%d nt=%d lds=%zu gc=%d | ticket+offs %.1f%% setup %.1f%% chunk-zero %.1f%% P1 %.1f%% P2 %.1f%% P3 %.1f%% final %.1f%% | total %.3g ticks/block\n",
                 blocks, nt, lds, P.gc, 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot,
                 100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot, tot / blocks);
-        if (z[7] && use_cells) fprintf(stderr, "[MF_STAMPS] cells kernel (if it ran): %d workgroups, cap %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% mask %.1f%% scan %.1f%% pass1 %.1f%% pass2 %.1f%% pass3 %.1f%% final %.1f%%\n",
-                          blocks_cells, cells_cap, tot / blocks_cells, (double)z[7], 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot, 100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot);
-        if (z[7]) fprintf(stderr, "[MF_STAMPS] dense kernel: %d workgroups, gc %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% barrier %.1f%% pass1 %.1f%% look-ups+barrier %.1f%% fetch issue %.1f%% pass2 %.1f%% pass3 %.1f%%\n", blocks_dense, dgc,
+        if (z[15]) {
+            const double totc = tot + (double)z[7];
+            fprintf(stderr, "[MF_STAMPS] cells kernel: %d workgroups, cap %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% mask %.1f%% scan %.1f%% pass1 %.1f%% pass2 %.1f%% pass3 %.1f%% rows-in+combine %.1f%% look-ups+rows-out %.1f%% | longest tile %.3g ticks; tiles >2048 records: %llu, mean %.3g ticks; 513..2048: %llu, %.3g; <=512: %llu, %.3g\n",
+                    blocks_cells, cells_cap, totc / blocks_cells, (double)z[15], 100 * z[0] / totc, 100 * z[1] / totc, 100 * z[2] / totc, 100 * z[3] / totc, 100 * z[4] / totc, 100 * z[5] / totc, 100 * z[7] / totc, 100 * z[6] / totc,
+                    (double)z[8], z[10], z[10] ? (double)z[9] / z[10] : 0.0, z[12], z[12] ? (double)z[11] / z[12] : 0.0, z[14], z[14] ? (double)z[13] / z[14] : 0.0);
+        }
+        if (z[7] && !z[15]) fprintf(stderr, "[MF_STAMPS] dense kernel: %d workgroups, gc %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% barrier %.1f%% pass1 %.1f%% look-ups+barrier %.1f%% fetch issue %.1f%% pass2 %.1f%% pass3 %.1f%%\n", blocks_dense, dgc,
                           tot / blocks_dense, (double)z[7], 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[6] / tot, 100 * z[2] / tot, 100 * z[5] / tot, 100 * z[3] / tot, 100 * z[4] / tot);
     }
     return MF_OK;
@@ -2838,7 +2961,7 @@ int mf_fuse_last_mode(const mf_grid *grid, int64_t n_points, int32_t n_groups, c
     int s0, s1, s2, a, b, c;
     // the layout of a call of frames (front end 0) with these arguments; class-id / ones kinds (the only ones
     // with a choice of tile kernel)
-    choose_tile(grid, n_groups, n_groups >= 2 && int_tiles_ok(grid, n_groups, MF_FEAT_ONES), s0, s1, s2);
+    choose_tile(grid, n_groups, n_groups >= 2 && int_tiles_ok(grid, n_groups, MF_FEAT_ONES, 0.5f), s0, s1, s2);
     Layout L;
     if (!make_layout(grid, n_points, n_groups, s0, s1, s2, L, a, b, c)) return fail(MF_ERR_INVALID, "problem too large");
     int mode = -1;
@@ -2902,10 +3025,10 @@ static int fuse_frames_phase(const mf_grid *grid, const mf_frames *frames, float
     return run_pipeline<0>(P, grid, workspace, workspace_bytes, (hipStream_t)stream, phase);
 }
 
-int mf_fuse_frames_stage(const mf_grid *grid, const mf_frames *frames, int32_t mode, void *workspace,
-                         size_t workspace_bytes, void *stream)
+int mf_fuse_frames_stage(const mf_grid *grid, const mf_frames *frames, float interpolation_weight, int32_t mode,
+                         void *workspace, size_t workspace_bytes, void *stream)
 {
-    return fuse_frames_phase(grid, frames, 0.0f, mode, workspace, workspace_bytes, stream, 1);
+    return fuse_frames_phase(grid, frames, interpolation_weight, mode, workspace, workspace_bytes, stream, 1);
 }
 
 int mf_fuse_frames_commit(const mf_grid *grid, const mf_frames *frames, float interpolation_weight, int32_t mode,

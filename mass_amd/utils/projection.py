@@ -312,7 +312,8 @@ class FusePipeline:
             self.side.wait_event(self.committed[slot])    # the workspace is free once its last commit is done
         with torch.cuda.stream(self.side):
             wptr, wbytes = self.ws[slot].get(need, self.device)
-            check(lib.mf_fuse_frames_stage(g, fr, mode, wptr, wbytes, _lib.c_void_p(self.side.cuda_stream)))
+            check(lib.mf_fuse_frames_stage(g, fr, float(interpolation_weight), mode, wptr, wbytes,
+                                           _lib.c_void_p(self.side.cuda_stream)))
             self.staged[slot].record(self.side)
         mine = (slot, g, fr, float(interpolation_weight), mode, wptr, wbytes, keep, fm)
         self._commit()                                    # the batch staged by the previous submit

@@ -11,5 +11,5 @@ import json
 d=json.load(open("gpurun_out/$tag/b_$name.json"))
 print("$name", "frames/s", round(d["value"]), "frac", round(d["roofline"]["frac"],3), "alone_ms", d["roofline"]["kernel_ms_unoverlapped"], {k: round(v,3) for k,v in d["roofline_step"]["stage_ms"].items()}, "parity", d.get("parity",{}).get("within_tolerance"), d.get("parity",{}).get("occupancy_bit_exact"))
 PY
-  MASSFUSE_LIB=$lib MF_STAMPS=1 timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-pipeline 2>&1 >/dev/null | grep "STAMPS. cells" | tail -1
+  MASSFUSE_LIB=$lib MF_STAMPS=1 timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-pipeline 2>&1 >/dev/null | grep "STAMPS. cells kernel:" | tail -1
 done
