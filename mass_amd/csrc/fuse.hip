@@ -1511,6 +1511,10 @@ constexpr int CELLS_MISC = 32 + 64;       // look-up words + per-frame cell coun
 #ifndef CELLS_RB_DEF
 #define CELLS_RB_DEF 512
 #endif
+#ifndef CELLS_EARLY_DEF
+#define CELLS_EARLY_DEF 1
+#endif
+constexpr bool CELLS_EARLY = CELLS_EARLY_DEF != 0;   // the tile's loads are issued at its start (else at the start of its final pass)
 constexpr int CELLS_RB = CELLS_RB_DEF;    // records of a tile kept in LDS per 256 threads (its first ones, fetched a tile ahead)
 
 template <int KIND, int S0, int S1, int S2, int NT, int F4, bool STAMPS = false>   // F4: float4s per lane and tile row (ceil(C 2^S2 / 256))
@@ -1631,6 +1635,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
     };
 
     prefetch_entries(misc[M_OFF], misc[M_OFF + 1]);
+    recbuf[tid] = pre0;
+    if (CEB == 2) recbuf[tid + NT] = pre1;
     const unsigned row_len = (unsigned)C << S2, row4 = row_len >> 2;
     const size_t row_stride = (size_t)P.size2 * C;                       // floats between map rows (x + 1)
 
@@ -1647,8 +1653,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         // of the corner code: slot k < RB from LDS, the rest of a heavy tile from memory.  (Kept in registers, the
         // copy needs a code path of its own per pass, and a select between the two makes the compiler spill it to
         // scratch memory and read both through flat loads.)
-        recbuf[tid] = pre0;
-        if (CEB == 2) recbuf[tid + NT] = pre1;
         auto for_records = [&](int ea, int eb, auto body) {
             const int k1 = eb - t_a;
 #pragma unroll 1
@@ -1673,6 +1677,38 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
 #pragma unroll
             for (int c = 0; c < 8; ++c) ci[c] = cb[c] + __popcll(mk[c] & wbelow);
         };
+
+        // All global loads of a tile: look-ups of the tiles ahead (wave 0), the next tile's first records, this tile's
+        // old rows (a wave takes whole rows: row, wave and the row's address are scalars; rows outside the map read row 0)
+        int p_rng_tile = -1, p_rng_off = 0, p_act = -1;
+        v4f oldv[RPW][F4];
+        float *grow[RPW];
+        auto issue_loads = [&]() {
+            if (tid < 64) {
+                p_rng_tile = act_pend;                           // (issued one tile ago, landed with that tile's rows)
+                p_rng_off = tile_range(p_rng_tile);
+                if (tk_next == tk_end) {                         // (uniform) a new batch of tickets, once per TK_BATCH tiles
+                    int tk = tid == 0 ? atomicAdd(P.ctr, TK_BATCH) : 0;
+                    tk_next = __shfl(tk, 0, 64);
+                    tk_end = tk_next + TK_BATCH;
+                }
+                p_act = resolve(tk_next++);
+            }
+            if (tile_n >= 0) prefetch_entries(tn_a, tn_b);       // (the record registers are free: their content is in LDS)
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                const int r = wave + q * NW;
+                const int l1 = r & ((1 << S1) - 1), l0 = r >> S1;
+                const bool in = r < N_ROWS && o0 + l0 < P.size0 && o1 + l1 < P.size1;
+                grow[q] = in ? P.map + ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * row_stride + (size_t)o2 * C : nullptr;
+#pragma unroll
+                for (int f = 0; f < F4; ++f) {
+                    const unsigned i4 = lane + 64 * f;
+                    oldv[q][f] = reinterpret_cast<const v4f *>(grow[q] ? grow[q] : P.map)[i4 < row4 ? i4 : 0];
+                }
+            }
+        };
+        if (CELLS_EARLY) issue_loads();
 
         bool first = true;
         for (int F = 0; F < G; F += 64) {                   // at most 64 frames share the voxels' masks
@@ -1807,37 +1843,16 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
             if (tid < TV) vox[tid].mask = 0ull;
             if (F + 64 < G) __syncthreads();                // the next frames' mask pass ORs into cleared masks
         }
-        // ---- final pass.  All global loads of the tile are issued here and waited for once.
+        // ---- final pass
+        if (!CELLS_EARLY) issue_loads();
         if (tid < 64) {
-            // look-ups: what was issued one tile ago has landed (it was covered by that tile's wait)
+            // look-ups, second half: the next tile becomes this one, the one after it is published, the registers move up
             if (tid <= 1) misc[M_OFF + tid] = tn_a * (1 - tid) + tn_b * tid;
             if (tid == 0) misc[M_NEXT] = nx_tile;
             if (tid <= 1) misc[M_OFFN + tid] = nx_off;
             nx_tile = rng_tile; nx_off = rng_off;
-            rng_tile = act_pend;
-            rng_off = tile_range(rng_tile);
-            if (tk_next == tk_end) {                            // (uniform) a new batch of tickets, once per TK_BATCH tiles
-                int tk = tid == 0 ? atomicAdd(P.ctr, TK_BATCH) : 0;
-                tk_next = __shfl(tk, 0, 64);
-                tk_end = tk_next + TK_BATCH;
-            }
-            act_pend = resolve(tk_next++);
-        }
-        if (tile_n >= 0) prefetch_entries(tn_a, tn_b);      // pass 3 is over: the register copy is free
-        // a wave takes whole tile rows (row, wave and the row's address are scalars); rows outside the map read row 0
-        v4f oldv[RPW][F4];
-        float *grow[RPW];
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const int r = wave + q * NW;
-            const int l1 = r & ((1 << S1) - 1), l0 = r >> S1;
-            const bool in = r < N_ROWS && o0 + l0 < P.size0 && o1 + l1 < P.size1;
-            grow[q] = in ? P.map + ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * row_stride + (size_t)o2 * C : nullptr;
-#pragma unroll
-            for (int f = 0; f < F4; ++f) {
-                const unsigned i4 = lane + 64 * f;
-                oldv[q][f] = reinterpret_cast<const v4f *>(grow[q] ? grow[q] : P.map)[i4 < row4 ? i4 : 0];
-            }
+            rng_tile = p_rng_tile; rng_off = p_rng_off;
+            act_pend = p_act;
         }
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
@@ -1861,6 +1876,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                     *reinterpret_cast<uint4 *>(d) = make_uint4(0u, 0u, 0u, 0u);
                 }
             }
+        }
+        // the next tile's first records (landed with the rows) go to this thread's LDS slots: pass 3 is over
+        if (tile_n >= 0) {
+            recbuf[tid] = pre0;
+            if (CEB == 2) recbuf[tid + NT] = pre1;
         }
         if (STAMPS && tid == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); stamp_acc[7] += _t - t_last; t_last = _t; }
 #pragma unroll

@@ -96,8 +96,8 @@ class SemanticProjectionLayer(BaseProjectionLayer):
             raise RuntimeError(self._CLASS_ERROR)
 
     def _update(self, observation, sequential, validate):
-        if validate == "defer":
-            self.check_labels(synchronize=False)         # whatever an earlier update has reported by now
+        if validate:
+            self.check_labels(synchronize=False)         # whatever an earlier (deferred) update has reported by now
         labels = self._labels(observation["semantic"])
         if validate is True and sequential and labels.dim() == 3 and labels.shape[0] > MAX_FRAMES_PER_CALL:
             # such a batch is issued in several library calls: look at all of its ids first, so that a raise
