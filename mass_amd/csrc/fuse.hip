@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
 constexpr int CELLS_FX = 31;              // fraction bits of the deltas
 constexpr int CELLS_MISC = 32 + 64;       // look-up words + per-frame cell counts of a window search
 #ifndef CELLS_RB_DEF
-#define CELLS_RB_DEF 512
+#define CELLS_RB_DEF 256
 #endif
 #ifndef CELLS_EARLY_DEF
 #define CELLS_EARLY_DEF 1
@@ -1534,7 +1534,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
     Vox *vox = reinterpret_cast<Vox *>(smem);                                        // [TV + 1] ([TV].cbase = cells in use)
     unsigned long long *cells = reinterpret_cast<unsigned long long *>(vox + TV + 1);   // [CAP + 1][2] W, S2; then (g, a); then t_f
     uint4 *recbuf = reinterpret_cast<uint4 *>(cells + (size_t)(CAP + 1) * 2);        // [RB] the tile's first records: thread t owns slots t + j NT
-    unsigned *Du = reinterpret_cast<unsigned *>(recbuf + RB);                        // [TV][C] deltas, units of 2^-CELLS_FX
+    uint4 *cibuf = recbuf + RB;                                                      // [RB] the cells of those records' corners (pass 1 -> pass 3), 16 bits each
+    unsigned *Du = reinterpret_cast<unsigned *>(cibuf + RB);                         // [TV][C] deltas, units of 2^-CELLS_FX
     int *misc = reinterpret_cast<int *>(Du + n_el);
     constexpr int M_TILE = 0, M_NEXT = 1, M_FIT = 2, M_EA = 3 /* [2] */, M_OFF = 6 /* [2] */, M_OFFN = 8 /* [2] */,
                   M_CLS = 12 /* [TILE_CLASSES] */, M_CNT = 32 /* [64] inclusive per-frame cell counts */;
@@ -1619,19 +1620,19 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
     };
     typedef float v4f __attribute__((ext_vector_type(4)));
     // exclusive scan of the voxels' cell counts inside the frame window `wm` (wave 0, TV / 64 voxels per lane)
+    // (every wave runs it and writes the same words: what a wave reads afterwards it has written itself, so no barrier
+    // is needed between the scan and the pass that follows)
     auto scan_cells = [&](unsigned long long wm) {
-        if (tid < 64) {
-            constexpr int VPL = TV / 64;
-            int n[VPL], tot = 0;
+        constexpr int VPL = TV / 64;
+        int n[VPL], tot = 0;
 #pragma unroll
-            for (int q = 0; q < VPL; ++q) { n[q] = __popcll(vox[VPL * tid + q].mask & wm); tot += n[q]; }
-            int inc = tot;
-            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (tid >= o) inc += y; }
-            int ex = inc - tot;
+        for (int q = 0; q < VPL; ++q) { n[q] = __popcll(vox[VPL * lane + q].mask & wm); tot += n[q]; }
+        int inc = tot;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+        int ex = inc - tot;
 #pragma unroll
-            for (int q = 0; q < VPL; ++q) { vox[VPL * tid + q].cbase = ex; ex += n[q]; }
-            if (tid == 63) vox[TV].cbase = inc;
-        }
+        for (int q = 0; q < VPL; ++q) { vox[VPL * lane + q].cbase = ex; ex += n[q]; }
+        if (lane == 63) vox[TV].cbase = inc;
     };
 
     prefetch_entries(misc[M_OFF], misc[M_OFF + 1]);
@@ -1661,21 +1662,18 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                 // (the empty asm keeps the two loads apart: merged, they become one flat load through a selected pointer)
                 if (k < RB) { r = recbuf[k]; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
                 else { r = P.rec[t_a + k]; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
-                if (t_a + k >= ea) body(r);
+                if (t_a + k >= ea) body(r, k);
             }
         };
         // cell of every corner of a record (a corner outside the tile reads voxel 0: the reads of all eight corners
         // are issued before the first is used, the atomics that follow are masked)
         auto corner_cells = [&](const MetaCorners<S1, S2> &m, unsigned long long wbelow, int (&ci)[8]) {
-            unsigned long long mk[8];
-            int cb[8];
+            uint4 x[8];                                     // {mask lo, mask hi, cell base, prod a}: one 16-byte read per corner
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const Vox *x = vox + ((m.in8 >> c) & 1u ? m.v[c] : 0);
-                mk[c] = x->mask; cb[c] = x->cbase;
-            }
+            for (int c = 0; c < 8; ++c) x[c] = reinterpret_cast<const uint4 *>(vox)[(m.in8 >> c) & 1u ? m.v[c] : 0];
+            const unsigned wlo = (unsigned)wbelow, whi = (unsigned)(wbelow >> 32);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) ci[c] = cb[c] + __popcll(mk[c] & wbelow);
+            for (int c = 0; c < 8; ++c) ci[c] = (int)x[c].z + __popc(x[c].x & wlo) + __popc(x[c].y & whi);
         };
 
         // All global loads of a tile: look-ups of the tiles ahead (wave 0), the next tile's first records, this tile's
@@ -1683,7 +1681,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         int p_rng_tile = -1, p_rng_off = 0, p_act = -1;
         v4f oldv[RPW][F4];
         float *grow[RPW];
-        auto issue_loads = [&]() {
+        auto issue_lookups = [&]() {                            // (at a point where every older load of the wave has landed)
             if (tid < 64) {
                 p_rng_tile = act_pend;                           // (issued one tile ago, landed with that tile's rows)
                 p_rng_off = tile_range(p_rng_tile);
@@ -1694,6 +1692,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                 }
                 p_act = resolve(tk_next++);
             }
+        };
+        auto issue_loads = [&]() {
             if (tile_n >= 0) prefetch_entries(tn_a, tn_b);       // (the record registers are free: their content is in LDS)
 #pragma unroll
             for (int q = 0; q < RPW; ++q) {
@@ -1722,7 +1722,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
             }
             if (sa >= sb) continue;                         // (uniform)
             // ---- mask pass: which of these frames touch which voxel
-            for_records(sa, sb, [&](const uint4 &r) {
+            for_records(sa, sb, [&](const uint4 &r, int) {
                 const MetaCorners<S1, S2> m(r);
                 const unsigned long long bit = 1ull << (meta_frame(r) - F);
 #pragma unroll
@@ -1732,7 +1732,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
             barrier_keep_vm();
             MF_STAMP(1)
             scan_cells(~0ull);
-            barrier_keep_vm();
             const bool split = vox[TV].cbase > CAP;         // (uniform) the cells of these frames do not fit at once
             if (split) {
                 // inclusive per-frame cell counts: a window is a run of frames whose cells fit
@@ -1764,11 +1763,14 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                 MF_STAMP(2)
                 if (ea < eb) {
                     // ---- pass 1: W, S2 of every cell
-                    for_records(ea, eb, [&](const uint4 &r) {
+                    for_records(ea, eb, [&](const uint4 &r, int k) {
                         const MetaCorners<S1, S2> m(r);
                         const int fl = meta_frame(r) - F;
                         int ci[8];
                         corner_cells(m, wm & ((1ull << fl) - 1ull), ci);
+                        if (k < RB)                              // kept for pass 3 (this thread's own slot)
+                            cibuf[k] = make_uint4((unsigned)ci[0] | (unsigned)ci[1] << 16, (unsigned)ci[2] | (unsigned)ci[3] << 16,
+                                                  (unsigned)ci[4] | (unsigned)ci[5] << 16, (unsigned)ci[6] | (unsigned)ci[7] << 16);
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
                             if ((m.in8 >> c) & 1u) {
@@ -1813,13 +1815,19 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                     barrier_keep_vm();
                     MF_STAMP(4)
                     // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1)
-                    for_records(ea, eb, [&](const uint4 &r) {
+                    for_records(ea, eb, [&](const uint4 &r, int k) {
                         const uint32_t x = meta_label(r);
                         if (KIND == 1 && x >= (uint32_t)C) return;
                         const MetaCorners<S1, S2> m(r);
-                        const int fl = meta_frame(r) - F;
                         int ci[8];
-                        corner_cells(m, wm & ((1ull << fl) - 1ull), ci);
+                        if (k < RB) {                            // (wave-uniform) the cells pass 1 found
+                            const uint4 q = cibuf[k];
+                            ci[0] = q.x & 0xffffu; ci[1] = q.x >> 16; ci[2] = q.y & 0xffffu; ci[3] = q.y >> 16;
+                            ci[4] = q.z & 0xffffu; ci[5] = q.z >> 16; ci[6] = q.w & 0xffffu; ci[7] = q.w >> 16;
+                        } else {
+                            const int fl = meta_frame(r) - F;
+                            corner_cells(m, wm & ((1ull << fl) - 1ull), ci);
+                        }
                         float t[8];
 #pragma unroll
                         for (int c = 0; c < 8; ++c) t[c] = klow(cells, 2 * ((m.in8 >> c) & 1u ? ci[c] : 0));
@@ -1845,15 +1853,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         }
         // ---- final pass
         if (!CELLS_EARLY) issue_loads();
-        if (tid < 64) {
-            // look-ups, second half: the next tile becomes this one, the one after it is published, the registers move up
-            if (tid <= 1) misc[M_OFF + tid] = tn_a * (1 - tid) + tn_b * tid;
-            if (tid == 0) misc[M_NEXT] = nx_tile;
-            if (tid <= 1) misc[M_OFFN + tid] = nx_off;
-            nx_tile = rng_tile; nx_off = rng_off;
-            rng_tile = p_rng_tile; rng_off = p_rng_off;
-            act_pend = p_act;
-        }
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
             const int r = wave + q * NW;
@@ -1876,6 +1875,17 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                     *reinterpret_cast<uint4 *>(d) = make_uint4(0u, 0u, 0u, 0u);
                 }
             }
+        }
+        // Look-ups of the tiles ahead: every load of this wave has landed (the rows were just used), so what was issued one
+        // tile ago costs no wait here (vmcnt retires in order), and what is issued now has a whole tile to come back.
+        issue_lookups();
+        if (tid < 64) {
+            if (tid <= 1) misc[M_OFF + tid] = tn_a * (1 - tid) + tn_b * tid;       // the next tile becomes this one,
+            if (tid == 0) misc[M_NEXT] = nx_tile;                                    // the one after it is published,
+            if (tid <= 1) misc[M_OFFN + tid] = nx_off;                               // the registers move up
+            nx_tile = rng_tile; nx_off = rng_off;
+            rng_tile = p_rng_tile; rng_off = p_rng_off;
+            act_pend = p_act;
         }
         // the next tile's first records (landed with the rows) go to this thread's LDS slots: pass 3 is over
         if (tile_n >= 0) {
@@ -2412,19 +2422,19 @@ constexpr int CELLS_SV = 7, CELLS_NT = 256;          // 4 x 4 x 8 tiles, 256 thr
 static size_t cells_lds_bytes(int C, int cap)
 {
     const size_t TV = (size_t)1 << CELLS_SV;
-    return (TV + 1) * 16 + (size_t)(cap + 1) * 16 + (size_t)CELLS_RB * (CELLS_NT / 256) * 16 + TV * C * 4 + CELLS_MISC * 4;
+    return (TV + 1) * 16 + (size_t)(cap + 1) * 16 + (size_t)CELLS_RB * (CELLS_NT / 256) * 32 + TV * C * 4 + CELLS_MISC * 4;
 }
 
 // Workgroups of fuse_cells_kernel per CU and the cells each of them holds: as many workgroups as leave each at
 // least 1,100 cells (a tile of a batch of unrelated frames needs ~600), eight at most (256 threads each).
-static bool cells_config(int C, int lds_per_cu, int &cap, int &per_cu)
+static bool cells_config(int C, int lds_per_cu, int reserve, int &cap, int &per_cu)
 {
     static const int forced = env_int("MF_CELLS_PER_CU", 1, 8, 0);            // dev
     if (C > 64) return false;                                                  // a tile row in two float4s per lane
     const size_t fixed = cells_lds_bytes(C, 0);
     for (per_cu = forced > 0 ? forced : 8; per_cu >= 1; --per_cu) {
-        const size_t budget = ((size_t)lds_per_cu / per_cu) & ~(size_t)1023;   // LDS is handed out in blocks
-        const size_t want = forced > 0 || per_cu == 1 ? (size_t)((1 << CELLS_SV) + 1) * 16 : (size_t)1100 * 16;
+        const size_t budget = ((size_t)(lds_per_cu - reserve) / per_cu) & ~(size_t)2047;   // LDS is handed out in blocks (three requests of 53 KB did not share a CU, three of 52 KB do)
+        const size_t want = forced > 0 || per_cu == 1 ? (size_t)((1 << CELLS_SV) + 1) * 16 : (size_t)800 * 16;
         if (budget < fixed + want) { if (forced > 0) return false; continue; }
         cap = (int)((budget - fixed) / 16) - 1;
         return cap >= (1 << CELLS_SV);          // a single frame's cells (one per voxel at most) always fit
@@ -2756,7 +2766,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     static const bool cells_forced = getenv("MF_CELLS_FORCE") != nullptr;
     int cells_cap = 0, cells_per_cu = 1;
     const bool use_cells = cells_on && dense_tiles && use_dense && sv == CELLS_SV && P.s2 == 3 && P.s0 == 2 && P.G >= 2 &&
-                           cells_config(P.C, dev.lds_per_cu, cells_cap, cells_per_cu);
+                           // (a commit on its own runs beside the bucketing kernels of the next batch: they need a few KB of LDS per CU)
+                           cells_config(P.C, dev.lds_per_cu, phase == 3 ? 0 : 8192, cells_cap, cells_per_cu);
     int blocks_cells = dev.cus * cells_per_cu;
     if (blocks_cap > 0 && blocks_cells > blocks_cap) blocks_cells = blocks_cap;
     if (blocks_cells > P.n_tiles) blocks_cells = P.n_tiles;
