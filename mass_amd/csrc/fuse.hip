@@ -1511,6 +1511,12 @@ constexpr int CELLS_MISC = 32 + 64;       // look-up words + per-frame cell coun
 #ifndef CELLS_RB_DEF
 #define CELLS_RB_DEF 256
 #endif
+#ifndef CELLS_SCANALL_DEF
+#define CELLS_SCANALL_DEF 1
+#endif
+#ifndef CELLS_CICACHE_DEF
+#define CELLS_CICACHE_DEF 1
+#endif
 #ifndef CELLS_EARLY_DEF
 #define CELLS_EARLY_DEF 1
 #endif
@@ -1623,6 +1629,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
     // (every wave runs it and writes the same words: what a wave reads afterwards it has written itself, so no barrier
     // is needed between the scan and the pass that follows)
     auto scan_cells = [&](unsigned long long wm) {
+        if (!CELLS_SCANALL_DEF && tid >= 64) return;
         constexpr int VPL = TV / 64;
         int n[VPL], tot = 0;
 #pragma unroll
@@ -1732,6 +1739,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
             barrier_keep_vm();
             MF_STAMP(1)
             scan_cells(~0ull);
+            // no workgroup barrier here (see scan_cells), but the compiler must not move the passes' 16-byte reads of the
+            // voxel words above the scan's 4-byte writes of the cell bases (different access types: it assumes no alias)
+            asm volatile("" ::: "memory");
+            if (!CELLS_SCANALL_DEF) barrier_keep_vm();
             const bool split = vox[TV].cbase > CAP;         // (uniform) the cells of these frames do not fit at once
             if (split) {
                 // inclusive per-frame cell counts: a window is a run of frames whose cells fit
@@ -1768,7 +1779,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                         const int fl = meta_frame(r) - F;
                         int ci[8];
                         corner_cells(m, wm & ((1ull << fl) - 1ull), ci);
-                        if (k < RB)                              // kept for pass 3 (this thread's own slot)
+                        if (CELLS_CICACHE_DEF && k < RB)         // kept for pass 3 (this thread's own slot)
                             cibuf[k] = make_uint4((unsigned)ci[0] | (unsigned)ci[1] << 16, (unsigned)ci[2] | (unsigned)ci[3] << 16,
                                                   (unsigned)ci[4] | (unsigned)ci[5] << 16, (unsigned)ci[6] | (unsigned)ci[7] << 16);
 #pragma unroll
@@ -1820,7 +1831,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                         if (KIND == 1 && x >= (uint32_t)C) return;
                         const MetaCorners<S1, S2> m(r);
                         int ci[8];
-                        if (k < RB) {                            // (wave-uniform) the cells pass 1 found
+                        if (CELLS_CICACHE_DEF && k < RB) {       // (wave-uniform) the cells pass 1 found
                             const uint4 q = cibuf[k];
                             ci[0] = q.x & 0xffffu; ci[1] = q.x >> 16; ci[2] = q.y & 0xffffu; ci[3] = q.y >> 16;
                             ci[4] = q.z & 0xffffu; ci[5] = q.z >> 16; ci[6] = q.w & 0xffffu; ci[7] = q.w >> 16;
