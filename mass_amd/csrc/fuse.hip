@@ -1518,19 +1518,21 @@ constexpr int CELLS_MISC = 32 + 64;       // look-up words + per-frame cell coun
 #define CELLS_CICACHE_DEF 1
 #endif
 #ifndef CELLS_EARLY_DEF
-#define CELLS_EARLY_DEF 1
+#define CELLS_EARLY_DEF 0
 #endif
 constexpr bool CELLS_EARLY = CELLS_EARLY_DEF != 0;   // the tile's loads are issued at its start (else at the start of its final pass)
 constexpr int CELLS_RB = CELLS_RB_DEF;    // records of a tile kept in LDS per 256 threads (its first ones, fetched a tile ahead)
 
-template <int KIND, int S0, int S1, int S2, int NT, int OVM, bool STAMPS = false>   // OVM: float4s of the tile image per thread (ceil(C 2^SV / 4 / NT))
+template <int KIND, int S0, int S1, int S2, int NT, int F4, bool STAMPS = false>   // F4: float4s per lane and tile row (ceil(C 2^S2 / 256))
 __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_cells_kernel(TileParams P)
 {
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-    constexpr int SV = S0 + S1 + S2, TV = 1 << SV, CEB = CELLS_RB / 256, RB = NT * CEB;
+    constexpr int SV = S0 + S1 + S2, TV = 1 << SV, NW = NT / 64, CEB = CELLS_RB / 256, RB = NT * CEB;
+    constexpr int N_ROWS = TV >> S2, RPW = (N_ROWS + NW - 1) / NW;          // tile rows, rows per wave
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = P.C, G = P.G, CAP = P.cells_cap;
     const unsigned n_el = (unsigned)TV * (unsigned)C;
     // LDS: per voxel {mask (u64), cell base, prod a}, cells, deltas, look-up words
@@ -1542,9 +1544,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
     unsigned *Du = reinterpret_cast<unsigned *>(cibuf + RB);                         // [TV][C] deltas, units of 2^-CELLS_FX
     int *misc = reinterpret_cast<int *>(Du + n_el);
     constexpr int M_TILE = 0, M_NEXT = 1, M_FIT = 2, M_EA = 3 /* [2] */, M_OFF = 6 /* [2] */, M_OFFN = 8 /* [2] */,
-                  M_CLS = 12 /* [TILE_CLASSES] */, M_BASE = 20 /* [3] this tile's float4 index in the map (lo, hi), border flag */,
-                  M_BASEN = 24 /* [3] the next tile's */, M_CNT = 32 /* [64] inclusive per-frame cell counts */;
-    static_assert(M_CLS + TILE_CLASSES <= M_BASE && M_BASEN + 3 <= M_CNT, "misc words");
+                  M_CLS = 12 /* [TILE_CLASSES] */, M_CNT = 32 /* [64] inclusive per-frame cell counts */;
+    static_assert(M_CLS + TILE_CLASSES <= 32, "misc words");
     const int fx_c = 182 - P.fx_shift;
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
     const float du_inv = __uint_as_float((unsigned)(127 - CELLS_FX) << 23);    // 2^-CELLS_FX
@@ -1577,17 +1578,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         if (t >= 0 && tid <= 1) o = bucket_start((t + tid) * G);
         return o;
     };
-    // Where a tile's image starts in the map (float4 index of its first row) and whether it reaches past the map's
-    // border in y or x: computed by ONE lane per tile (three integer divisions) and handed to the workgroup through LDS.
-    auto publish_base = [&](int slot, int t) {
-        if (t < 0) return;
-        const int tz = t % P.nt2, ty = (t / P.nt2) % P.nt1, tx = t / (P.nt2 * P.nt1);
-        const int o0 = tx << S0, o1 = ty << S1, o2 = tz << S2;
-        const unsigned long long b4 = ((((unsigned long long)o0 * P.size1 + o1) * P.size2 + o2) * (unsigned)C) >> 2;
-        misc[slot] = (int)(unsigned)b4;
-        misc[slot + 1] = (int)(unsigned)(b4 >> 32);
-        misc[slot + 2] = (o0 + (1 << S0) > P.size0 || o1 + (1 << S1) > P.size1) ? 1 : 0;
-    };
     // Look-ups of the tiles ahead (ticket -> work list entry -> record range: dependent global round trips) are
     // made by wave 0, one stage per tile, at the start of the final pass.
     int tk_next = 0, tk_end = 0, act_pend = -1, rng_tile = -1, rng_off = 0, nx_tile = -1, nx_off = 0;
@@ -1611,7 +1601,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         tk_next = tk + 4; tk_end = tk + TK_BATCH;
         const int t0 = resolve(b), t1 = resolve(tk);
         const int o0 = tile_range(t0), o1 = tile_range(t1);
-        if (tid == 0) { misc[M_TILE] = t0; misc[M_NEXT] = t1; publish_base(M_BASE, t0); publish_base(M_BASEN, t1); }
+        if (tid == 0) { misc[M_TILE] = t0; misc[M_NEXT] = t1; }
         if (tid <= 1) { misc[M_OFF + tid] = o0; misc[M_OFFN + tid] = o1; }
         nx_tile = resolve(tk + 1);
         nx_off = tile_range(nx_tile);
@@ -1630,6 +1620,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         pre0 = P.rec[min(ta + tid, tb - 1)];
         if (CEB == 2) pre1 = P.rec[min(ta + tid + NT, tb - 1)];
     };
+    auto tile_origin = [&](int t, int &o0, int &o1, int &o2) {
+        const int tz = t % P.nt2, ty = (t / P.nt2) % P.nt1, tx = t / (P.nt2 * P.nt1);
+        o0 = tx << S0; o1 = ty << S1; o2 = tz << S2;
+    };
+    typedef float v4f __attribute__((ext_vector_type(4)));
     // exclusive scan of the voxels' cell counts inside the frame window `wm` (wave 0, TV / 64 voxels per lane)
     // (every wave runs it and writes the same words: what a wave reads afterwards it has written itself, so no barrier
     // is needed between the scan and the pass that follows)
@@ -1650,35 +1645,15 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
     prefetch_entries(misc[M_OFF], misc[M_OFF + 1]);
     recbuf[tid] = pre0;
     if (CEB == 2) recbuf[tid + NT] = pre1;
-    // The float4s of the tile image this thread owns (q = tid + j NT): where they sit relative to the tile's first row,
-    // which voxels their four floats belong to (two at most when C >= 4) and which tile row they are in: the same for
-    // every tile, so worked out once.  A tile then needs one base address (from LDS) and no address arithmetic.
-    const unsigned row_len = (unsigned)C << S2;
-    const unsigned n4 = n_el >> 2;
-    unsigned rel4[OVM];            // float4 offset from the tile's first row
-    unsigned vpk[OVM];             // voxel of float 0 | voxel of float 3 << 8 | first float of the second voxel (1..4; 4 = none) << 16 | (l0 << 4 | l1) << 24
-#pragma unroll
-    for (int j = 0; j < OVM; ++j) {
-        const unsigned q = min((unsigned)(tid + j * NT), n4 - 1u), i = q << 2;
-        const unsigned r = div_magic(i, P.magicC) >> S2;                   // tile row (l0, l1)
-        const unsigned l1 = r & ((1u << S1) - 1u), l0 = r >> S1;
-        const unsigned in_row = i - r * row_len;
-        rel4[j] = (unsigned)((((size_t)l0 * P.size1 + l1) * P.size2 * C + in_row) >> 2);
-        const unsigned v0 = div_magic(i, P.magicC), v3 = div_magic(i + 3, P.magicC);
-        unsigned ks = 4u;
-        if (v3 != v0) ks = (v0 + 1u) * C - i;                               // first float that belongs to v3 (C >= 4: v3 <= v0 + 1)
-        vpk[j] = v0 | (v3 << 8) | (ks << 16) | ((l0 << 4 | l1) << 24);
-    }
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f *map4 = reinterpret_cast<v4f *>(P.map);
+    const unsigned row_len = (unsigned)C << S2, row4 = row_len >> 2;
+    const size_t row_stride = (size_t)P.size2 * C;                       // floats between map rows (x + 1)
 
     while (true) {
+        int o0, o1, o2;
+        tile_origin(tile, o0, o1, o2);
         const int t_a = __builtin_amdgcn_readfirstlane(misc[M_OFF]), t_b = __builtin_amdgcn_readfirstlane(misc[M_OFF + 1]);
         const int tile_n = __builtin_amdgcn_readfirstlane(misc[M_NEXT]);
         const int tn_a = __builtin_amdgcn_readfirstlane(misc[M_OFFN]), tn_b = __builtin_amdgcn_readfirstlane(misc[M_OFFN + 1]);
-        const unsigned long long base4 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(misc[M_BASE]) |
-                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(misc[M_BASE + 1]) << 32;
-        const bool border = __builtin_amdgcn_readfirstlane(misc[M_BASE + 2]) != 0;
         const unsigned long long t_tile = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
         MF_STAMP(0)
         // The tile's first RB records were fetched one tile ahead (registers); they go to this thread's own LDS slots
@@ -1688,12 +1663,17 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         // scratch memory and read both through flat loads.)
         auto for_records = [&](int ea, int eb, auto body) {
             const int k1 = eb - t_a;
+            int k = (ea - t_a) / NT * NT + tid;                                // k: index inside the tile; k < RB is uniform
+            uint4 gn = make_uint4(0u, 0u, 0u, 0u);                              // a heavy tile's record of the NEXT trip:
+            if (k >= RB && k < k1) gn = P.rec[t_a + k];                         // loaded one trip ahead, so that the
 #pragma unroll 1
-            for (int k = (ea - t_a) / NT * NT + tid; k < k1; k += NT) {       // k: index inside the tile; k < RB is wave-uniform
+            for (; k < k1; k += NT) {                                           // memory round trip runs beside the body
                 uint4 r;
-                // (the empty asm keeps the two loads apart: merged, they become one flat load through a selected pointer)
+                // (the empty asm keeps the two sources apart: merged, they become one flat load through a selected pointer)
                 if (k < RB) { r = recbuf[k]; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
-                else { r = P.rec[t_a + k]; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
+                else { r = gn; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
+                const int kn = k + NT;
+                if (kn >= RB && kn < k1) gn = P.rec[t_a + kn];
                 if (t_a + k >= ea) body(r, k);
             }
         };
@@ -1711,19 +1691,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         // All global loads of a tile: look-ups of the tiles ahead (wave 0), the next tile's first records, this tile's
         // old rows (a wave takes whole rows: row, wave and the row's address are scalars; rows outside the map read row 0)
         int p_rng_tile = -1, p_rng_off = 0, p_act = -1;
-        v4f oldv[OVM];
-        // which of this thread's float4s lie inside the map: all of them, except in a tile that reaches past the map's
-        // border in y or x (uniform and rare: the tile's origin is worked out again there)
-        unsigned inmask = (1u << OVM) - 1u;
-        if (border) {
-            const int ty = (tile / P.nt2) % P.nt1, tx = tile / (P.nt2 * P.nt1);
-            inmask = 0u;
-#pragma unroll
-            for (int j = 0; j < OVM; ++j) {
-                const unsigned l0 = vpk[j] >> 28, l1 = (vpk[j] >> 24) & 15u;
-                if ((tx << S0) + (int)l0 < P.size0 && (ty << S1) + (int)l1 < P.size1) inmask |= 1u << j;
-            }
-        }
+        v4f oldv[RPW][F4];
+        float *grow[RPW];
         auto issue_lookups = [&]() {                            // (at a point where every older load of the wave has landed)
             if (tid < 64) {
                 p_rng_tile = act_pend;                           // (issued one tile ago, landed with that tile's rows)
@@ -1739,18 +1708,22 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         auto issue_loads = [&]() {
             if (tile_n >= 0) prefetch_entries(tn_a, tn_b);       // (the record registers are free: their content is in LDS)
 #pragma unroll
-            for (int j = 0; j < OVM; ++j)                         // unconditional: a float4 outside the map reads the tile's first one
-                oldv[j] = map4[base4 + ((inmask >> j) & 1u ? rel4[j] : 0u)];
+            for (int q = 0; q < RPW; ++q) {
+                const int r = wave + q * NW;
+                const int l1 = r & ((1 << S1) - 1), l0 = r >> S1;
+                const bool in = r < N_ROWS && o0 + l0 < P.size0 && o1 + l1 < P.size1;
+                grow[q] = in ? P.map + ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * row_stride + (size_t)o2 * C : nullptr;
+#pragma unroll
+                for (int f = 0; f < F4; ++f) {
+                    const unsigned i4 = lane + 64 * f;
+                    oldv[q][f] = reinterpret_cast<const v4f *>(grow[q] ? grow[q] : P.map)[i4 < row4 ? i4 : 0];
+                }
+            }
         };
         if (CELLS_EARLY) issue_loads();
 
         bool first = true;
-#ifdef CELLS_SKIP_PASSES   /* dev: the memory side alone (rows in, rows out, look-ups) */
-        if (tid < TV) vox[tid].atot = 1.0f;
-        for (int F = G; F < G; F += 64) {
-#else
         for (int F = 0; F < G; F += 64) {                   // at most 64 frames share the voxels' masks
-#endif
             const int nf = min(64, G - F);
             int sa = t_a, sb = t_b;
             if (G > 64) {                                   // part of the tile's frames: look its record range up
@@ -1897,25 +1870,25 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         // ---- final pass
         if (!CELLS_EARLY) issue_loads();
 #pragma unroll
-        for (int j = 0; j < OVM; ++j) {
-            const unsigned q = tid + j * NT;
-            if (q < n4) {
-                uint4 *d = reinterpret_cast<uint4 *>(Du) + q;
-                const uint4 dq = *d;
-                *d = make_uint4(0u, 0u, 0u, 0u);
-                if (C >= 4) {                                     // (uniform) a float4 spans two voxels at most
-                    const float a0 = vox[vpk[j] & 255u].atot, a3 = vox[(vpk[j] >> 8) & 255u].atot;
-                    const unsigned ks = (vpk[j] >> 16) & 7u;
-                    oldv[j][0] = oldv[j][0] * a0 + (float)dq.x * du_inv;
-                    oldv[j][1] = oldv[j][1] * (ks <= 1u ? a3 : a0) + (float)dq.y * du_inv;
-                    oldv[j][2] = oldv[j][2] * (ks <= 2u ? a3 : a0) + (float)dq.z * du_inv;
-                    oldv[j][3] = oldv[j][3] * (ks <= 3u ? a3 : a0) + (float)dq.w * du_inv;
-                } else {
-                    const unsigned i = q << 2;
-                    oldv[j][0] = oldv[j][0] * vox[div_magic(i, P.magicC)].atot + (float)dq.x * du_inv;
-                    oldv[j][1] = oldv[j][1] * vox[div_magic(i + 1, P.magicC)].atot + (float)dq.y * du_inv;
-                    oldv[j][2] = oldv[j][2] * vox[div_magic(i + 2, P.magicC)].atot + (float)dq.z * du_inv;
-                    oldv[j][3] = oldv[j][3] * vox[div_magic(i + 3, P.magicC)].atot + (float)dq.w * du_inv;
+        for (int q = 0; q < RPW; ++q) {
+            const int r = wave + q * NW;
+#pragma unroll
+            for (int f = 0; f < F4; ++f) {
+                const unsigned i4 = lane + 64 * f;
+                if (grow[q] && i4 < row4) {
+                    const unsigned i = i4 << 2;                                   // float index inside the row
+                    const unsigned v0 = div_magic(i, P.magicC), rem = i - v0 * C;
+                    unsigned vv[4];
+                    vv[0] = v0;
+                    if (C >= 4) { vv[1] = v0 + (rem + 1 >= (unsigned)C); vv[2] = v0 + (rem + 2 >= (unsigned)C); vv[3] = v0 + (rem + 3 >= (unsigned)C); }
+                    else { vv[1] = div_magic(i + 1, P.magicC); vv[2] = div_magic(i + 2, P.magicC); vv[3] = div_magic(i + 3, P.magicC); }
+                    unsigned *d = Du + (unsigned)r * row_len + i;
+                    const uint4 dq = *reinterpret_cast<const uint4 *>(d);
+                    const unsigned dd[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        oldv[q][f][k] = oldv[q][f][k] * vox[(r << S2) + vv[k]].atot + (float)dd[k] * du_inv;
+                    *reinterpret_cast<uint4 *>(d) = make_uint4(0u, 0u, 0u, 0u);
                 }
             }
         }
@@ -1924,8 +1897,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         issue_lookups();
         if (tid < 64) {
             if (tid <= 1) misc[M_OFF + tid] = tn_a * (1 - tid) + tn_b * tid;       // the next tile becomes this one,
-            if (tid <= 2) misc[M_BASE + tid] = misc[M_BASEN + tid];
-            if (tid == 0) { misc[M_NEXT] = nx_tile; publish_base(M_BASEN, nx_tile); }  // the one after it is published,
+            if (tid == 0) misc[M_NEXT] = nx_tile;                                    // the one after it is published,
             if (tid <= 1) misc[M_OFFN + tid] = nx_off;                               // the registers move up
             nx_tile = rng_tile; nx_off = rng_off;
             rng_tile = p_rng_tile; rng_off = p_rng_off;
@@ -1938,8 +1910,12 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
         }
         if (STAMPS && tid == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); stamp_acc[7] += _t - t_last; t_last = _t; }
 #pragma unroll
-        for (int j = 0; j < OVM; ++j)
-            if ((unsigned)(tid + j * NT) < n4 && ((inmask >> j) & 1u)) map4[base4 + rel4[j]] = oldv[j];
+        for (int q = 0; q < RPW; ++q)
+#pragma unroll
+            for (int f = 0; f < F4; ++f) {
+                const unsigned i4 = lane + 64 * f;
+                if (grow[q] && i4 < row4) reinterpret_cast<v4f *>(grow[q])[i4] = oldv[q][f];
+            }
         MF_STAMP(6)
         if (STAMPS && tid == 0) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_tile;
@@ -2919,12 +2895,11 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         MF_LAUNCH_CHECK("fuse_dense_kernel");
     }
     if (use_cells) {
-        const int ovm = (int)((((size_t)P.C << CELLS_SV) / 4 + CELLS_NT - 1) / CELLS_NT);   // float4s of the tile image per thread
+        const int f4 = (int)((((size_t)P.C << 3) / 4 + 63) / 64);          // float4s per lane and tile row
         void (*ck)(TileParams);
         if (kind == 0) ck = stamps ? fuse_cells_kernel<0, 2, 2, 3, CELLS_NT, 1, true> : fuse_cells_kernel<0, 2, 2, 3, CELLS_NT, 1>;
-        else if (ovm <= 4) ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 4, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 4>;
-        else if (ovm <= 7) ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 7, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 7>;
-        else ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 8, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 8>;
+        else if (f4 <= 1) ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 1, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 1>;
+        else ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 2, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 2>;
         const size_t clds = cells_lds_bytes(P.C, cells_cap);
         {
             static std::mutex mu4;
