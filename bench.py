@@ -51,9 +51,15 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--workload", default="distA", choices=["distA", "room"])
+    ap.add_argument("--workload", default="distA", choices=["distA", "room", "episode"],
+                    help="distA / room: configs[1] batches (distribution A is the headline); episode: configs[4], every rank "
+                         "runs its share of --episodes synthetic episodes (two 300-frame maps + matching each), a step = one round")
+    ap.add_argument("--episodes", type=int, default=8)
+    ap.add_argument("--episode-frames", type=int, default=300)
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct resident batches per rank, taken in turn (inputs + records exceed the 256 MB Infinity Cache)")
     ap.add_argument("--mode", default="sequential", choices=["sequential", "merged"])
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames per repetition of the CPU oracle (1 warm + 3 timed)")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames per repetition of the CPU oracle (1 warm + 3 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other SURVEY 8(d) workloads (rank 0, N = 1)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -133,45 +139,96 @@ def cpu_model():
 
 
 def cpu_baseline(frames, per_rep, reps=3):
-    """The oracle (oracle/massref.c, scalar C port of the reference algorithm, 1 thread) on the
-    first (1 + reps) * per_rep frames of rank 0's batch, sequential, same map size: one warm
-    repetition, then `reps` timed ones; the median rate is reported.  Returns the baseline
-    record and the oracle layer (its map is what the GPU parity check compares with)."""
+    """The oracle (oracle/massref.c, C port of the reference algorithm) on the first (1 + reps) * per_rep frames
+    of rank 0's batch, sequential, same map size, on all host threads it may use (its blend loop is threaded so that
+    the result is bit-identical to the single thread): one warm repetition, then `reps` timed ones; the median rate
+    is `value`.  The single-thread rate of the same code is measured on a few more frames and reported beside it.
+    Returns the baseline record, the oracle layer (its map after the multi-thread frames is what the GPU parity
+    check compares with) and the number of frames it holds."""
     from oracle import massref as orc
     lay = orc.RefProjectionLayer(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
                                  feature_size=C, grid_resolution=0.05)
+    threads = orc.get_threads()
     n = (1 + reps) * per_rep
-    obs = [dict(position=frames["position"][f], yaw=frames["yaw"][f], elevation=frames["elevation"][f],
-                depth=frames["depth"][f],
-                features=torch.nn.functional.one_hot(frames["semantic"][f].long(), C).float()) for f in range(n)]
+
+    def obs(f):
+        return dict(position=frames["position"][f], yaw=frames["yaw"][f], elevation=frames["elevation"][f],
+                    depth=frames["depth"][f], features=torch.nn.functional.one_hot(frames["semantic"][f].long(), C).float())
     rates, total = [], 0.0
     for r in range(1 + reps):
+        batch = [obs(f) for f in range(r * per_rep, (r + 1) * per_rep)]        # the one-hot images are built outside the timing
         t0 = time.perf_counter()
-        for o in obs[r * per_rep:(r + 1) * per_rep]:
+        for o in batch:
             lay.update(o)
         dt = time.perf_counter() - t0
         total += dt
         if r > 0:
             rates.append(per_rep / dt)
-    rec = dict(value=statistics.median(rates), unit="frames/s", cores=1, kind="port",
-               reps=reps, rates=[round(x, 4) for x in rates], cpu_model=cpu_model(), host_cpus=os.cpu_count(),
+    # single thread, on a copy of the map (so that the parity map stays the one after n frames)
+    single = None
+    n1 = min(3, max(frames["depth"].shape[0] - n, 0))
+    if n1 > 0:
+        lay1 = orc.RefProjectionLayer(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
+                                      feature_size=C, grid_resolution=0.05)
+        lay1.data.copy_(lay.data)
+        batch = [obs(f) for f in range(n, n + n1)]
+        orc.set_threads(1)
+        try:
+            t0 = time.perf_counter()
+            for o in batch:
+                lay1.update(o)
+            single = n1 / (time.perf_counter() - t0)
+        finally:
+            orc.set_threads(threads)
+        del lay1
+    rec = dict(value=statistics.median(rates), unit="frames/s", cores=threads, kind="port",
+               reps=reps, rates=[round(x, 4) for x in rates], single_thread_frames_per_s=single,
+               cpu_model=cpu_model(), host_cpus=os.cpu_count(),
                torch_threads=torch.get_num_threads(), torch=torch.__version__,
                sample=f"frames {per_rep}..{n - 1} of rank 0's batch through oracle/massref.c (bin_rays + "
                       f"update_feature_map on one-hot fp32 features as the reference builds them), sequential "
                       f"onto one {MAP}^3 x {C} map: 1 warm + {reps} timed repetitions of {per_rep} frames, median; "
-                      f"{total:.1f} s of CPU work, single thread (scalar port)",
+                      f"{total:.1f} s of CPU work on {threads} threads (OpenMP over the touched voxels, bit-identical to "
+                      f"one thread); single_thread_frames_per_s: the next {n1} frames on one thread",
                reference_in_build_container="0.52 frames/s (the reference's own torch CPU path, 8 threads, "
                                             "256^3 x 54; SURVEY section 6)")
     return rec, lay, n
 
 
-def parity_vs_oracle(lay_kw, frames, n, ref_layer, dev):
-    """Untimed: the first n frames of the batch through the HIP pipeline onto a fresh map,
-    compared with the oracle map cpu_baseline() built from the same frames."""
+MODE_NAMES = {0: "fuse_tiles_kernel", 2: "fuse_dense_kernel", 3: "fuse_cells_kernel"}
+
+
+def last_mode(lay, n_frames, ws=None):
+    """Which tile kernel took the last sequential multi-frame call on this layer's (or the given) workspace."""
+    from mass_amd import _lib
+    from mass_amd.utils.projection import _grid_struct
+    g = _grid_struct(lay.data, lay.bins_x, lay.bins_y, lay.bins_z)
+    wptr, _ = (ws or lay._workspace).get(1, lay.data.device)
+    m = _lib.lib.mf_fuse_last_mode(g, n_frames * H * W, n_frames, wptr, _lib.current_stream(lay.data.device))
+    return MODE_NAMES.get(m, str(m))
+
+
+def parity_vs_oracle(lay_kw, frames, n, ref_layer, dev, pipelined):
+    """Untimed: the first n frames of the batch onto a fresh map through the SAME issue path the timed steps take
+    (pipelined: two FusePipeline submits of n / 2 frames, stage on the side stream + commit alone; else one
+    mf_fuse_frames call), compared with the oracle map of the same frames."""
     from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    from mass_amd.utils.projection import FusePipeline
     lay = SemanticProjectionLayer(**lay_kw).to(dev)
-    lay.update_batch(dict(position=frames["position"][:n], yaw=frames["yaw"][:n], elevation=frames["elevation"][:n],
-                          depth=frames["depth"][:n].to(dev), semantic=frames["semantic"][:n].to(dev)), sequential=True)
+    depth, sem = frames["depth"][:n].to(dev).reshape(n, H, W), frames["semantic"][:n].to(dev)
+    if pipelined and n >= 4:
+        pipe, h = FusePipeline(dev), n // 2
+        for sl in (slice(0, h), slice(h, n)):
+            poses = lay._poses(frames["position"][sl], frames["yaw"][sl], frames["elevation"][sl])
+            pipe.submit(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth[sl], sem[sl], lay.data,
+                        interpolation_weight=lay.interpolation_weight, sequential=True)
+        pipe.flush()
+        kernel = last_mode(lay, n - h, pipe.ws[1])
+    else:
+        lay.update_batch(dict(position=frames["position"][:n], yaw=frames["yaw"][:n], elevation=frames["elevation"][:n],
+                              depth=depth, semantic=sem), sequential=True)
+        kernel = last_mode(lay, n)
+    torch.cuda.synchronize()
     occ_equal, ok, rel, occupied = True, True, 0.0, 0
     for y0 in range(0, MAP, 32):                       # compared on the device, slab by slab, in fp64
         got = lay.data[y0:y0 + 32].to(torch.float64)
@@ -184,7 +241,35 @@ def parity_vs_oracle(lay_kw, frames, n, ref_layer, dev):
     del lay
     return dict(parity_checked_frames=n, occupancy_bit_exact=occ_equal, within_tolerance=ok,
                 tolerance="|got - want| <= 1e-4 |want| + 1e-6", max_scaled_err=rel, occupied_voxels=occupied,
-                note="GPU map after the first n frames (one sequential launch) vs the oracle map of the same frames")
+                tile_kernel=kernel, issue="pipelined (two stage / commit pairs)" if pipelined and n >= 4 else "one call",
+                note="GPU map after the first n frames, issued like the timed steps, vs the oracle map of the same frames")
+
+
+def oracle_map(frames, n):
+    """The oracle's map after the first n frames (threads as available: bit-identical to one thread)."""
+    from oracle import massref as orc
+    lay = orc.RefProjectionLayer(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
+                                 feature_size=C, grid_resolution=0.05)
+    for f in range(n):
+        lay.update(dict(position=frames["position"][f], yaw=frames["yaw"][f], elevation=frames["elevation"][f],
+                        depth=frames["depth"][f], features=torch.nn.functional.one_hot(frames["semantic"][f].long(), C).float()))
+    return lay
+
+
+def copy_bandwidth(dev, nbytes=1 << 30, reps=5):
+    """Achieved HBM copy bandwidth of this GPU in this run (GB/s, read + write bytes): a 1 GiB device-to-device copy."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    del a, b
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def sources_sha():
@@ -275,7 +360,8 @@ def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
         torch.cuda.synchronize()
         wall_p = time.perf_counter() - t0
         del pipe
-        out[name] = dict(frames_per_s=B * steps / wall, ms_per_step=wall / steps * 1e3, stage_ms=st,
+        out[name] = dict(tile_kernel=last_mode(lay, B if sequential else 1) if sequential else "fuse_dense_kernel / single-pass (merged: one group)",
+                         frames_per_s=B * steps / wall, ms_per_step=wall / steps * 1e3, stage_ms=st,
                          frames_per_s_pipelined=B * steps / wall_p, ms_per_step_pipelined=wall_p / steps * 1e3,
                          union_voxels=union, touched_voxels_per_frame_mean=float(np.mean(T)),
                          algorithmic_bytes_per_launch=step_bytes,
@@ -296,6 +382,10 @@ def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
     label_b = tr["semantic"].to(dev).contiguous()
     batch_run("distB_sequential_b64", tr, poses_b, depth_b, label_b, True)
     del depth_b, label_b
+    # ... and its parity at this shape, through the pipelined issue path: first 16 frames vs the oracle
+    ref_b = oracle_map(tr, 16)
+    out["distB_sequential_b64"]["parity"] = parity_vs_oracle(lay_kw, tr, 16, ref_b, dev, True)
+    del ref_b
 
     # configs[2]: 300-frame room trajectory, three maps updated per frame through layer.update()
     # (occupancy C = 1, semantic C = 54, "RGB" C = 3 dense), as agent.py:107-111 drives them
@@ -372,10 +462,91 @@ def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
     res["note"] = ("82 MFLOP contraction: launch-latency bound, no roofline claim (SURVEY 8d); l2 = the reference's "
                    "difference form, l2_gemm = norm expansion on fp32 MFMA; assignment on the host like the reference")
     out["config4_matching_200x200x1024"] = res
+
+    # the whole-map reductions the callers run on .data (navigation_policy.py:208-221, agent.py:330-331):
+    # pure HBM scans, priced against the bytes they have to read
+    from mass_amd.utils.reductions import amax_z, column_occupied
+    sem = SemanticProjectionLayer(**lay_kw).to(dev)
+    sem.data.normal_()
+    occ = OccupancyProjectionLayer(**{k: v for k, v in lay_kw.items() if k != "feature_size"}).to(dev)
+    occ.data.uniform_()
+    red = {}
+    for name, fn, nbytes in (("amax_z_256x256x256x54", lambda: amax_z(sem.data), sem.data.numel() * 4 + MAP * MAP * C * 4),
+                             ("column_occupied_occupancy_256^3", lambda: column_occupied(occ.data, None, 0.5), occ.data.numel() * 4 + MAP * MAP)):
+        try:
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            red[name] = dict(ms=ms, algorithmic_bytes=nbytes, GBps=nbytes / (ms * 1e-3) / 1e9,
+                             frac_of_hbm_peak=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        except Exception as exc:          # a reduction failing must not lose the headline line
+            red[name] = dict(error=repr(exc))
+    out["f2_whole_map_reductions"] = red
     return out
 
 
 # ----------------------------------------------------------------------------------------------
+def run_episode_rank(args, rank, world, dev, D):
+    """BASELINE configs[4]: --episodes synthetic episodes sharded over the ranks like the
+    reference shards tasks (agent.py:154-155: episode e on rank e mod world), each a walkthrough and an unshuffle
+    semantic map of --episode-frames room frames (seeds 1000 e + phase) fused in sequential 64-frame batches, then
+    predict_scene_differences; the per-rank counters are summed by ONE all-reduce at the end (RCCL).  A step is one
+    round over the rank's episodes; the frames are resident in HBM before the timed region."""
+    from mass_amd.episodes import shard_episodes, prepare_episode, make_episode_layers, run_episode
+    mine = shard_episodes(args.episodes, rank, world)
+    prepared = [prepare_episode(e, dev, args.episode_frames, H, W, C) for e in mine]
+    layers = make_episode_layers(dev, H, W, MAP, C, 0.05)
+
+    def barrier():
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+
+    def round_():
+        tot = {}
+        for p in prepared:
+            for k, v in run_episode(p, layers, batch=args.batch).items():
+                tot[k] = tot.get(k, 0.0) + v
+        return tot
+    for _ in range(args.warmup):
+        round_()
+    barrier()
+    t0 = time.perf_counter()
+    counters = {}
+    for _ in range(args.steps):
+        counters = round_()
+    barrier()
+    wall = time.perf_counter() - t0
+    wall_max = D.max_over_ranks(wall)
+    for k in ("episodes", "frames", "moved_found", "n_matches", "shift_m", "occupied_voxels", "map_abs_sum"):
+        counters.setdefault(k, 0.0)                      # a rank without episodes still takes part in the all-reduce
+    metrics = D.reduce_metrics(counters)                 # the run's one data collective
+    if rank == 0:
+        frames_total = metrics["frames"] * args.steps
+        print(json.dumps({
+            "metric": "RGB-D frames/s fused into 256^3 semantic voxel map", "value": frames_total / wall_max,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[4]: {args.episodes} synthetic episodes (walkthrough + unshuffle semantic map, "
+                                   f"{args.episode_frames} room frames each, 480x640 -> 256^3 x 54, sequential batches of "
+                                   f"{args.batch}) + predict_scene_differences, episodes sharded over the ranks, one metrics "
+                                   f"all-reduce", "episodes": args.episodes, "frames_per_episode": 2 * args.episode_frames},
+            "metrics_allreduce": metrics,
+            "note": "strong scaling: the episode count is fixed, ranks share it; includes find() + matching per episode"}),
+            flush=True)
+    if world > 1:
+        D.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def run_rank(args):
     from mass_amd import distributed as D
     # nccl == RCCL on ROCm.  MF_BENCH_BACKEND=gloo is a rehearsal knob for boxes with fewer GPUs
@@ -393,25 +564,36 @@ def run_rank(args):
 
     lay_kw = dict(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
                   feature_size=C, grid_resolution=0.05)
+    if args.workload == "episode":
+        return run_episode_rank(args, rank, world, dev, D)
     lay = SemanticProjectionLayer(**lay_kw).train().to(dev)
     stride = args.batch if args.rank_seed_stride < 0 else args.rank_seed_stride
-    frames = make_frames(args.workload, args.batch, seed0=rank * stride)
-    poses = lay._poses(frames["position"], frames["yaw"], frames["elevation"])
-    depth = frames["depth"].to(dev).reshape(args.batch, H, W).contiguous()
-    label = frames["semantic"].to(dev).contiguous()
+    # `rotate` distinct resident batches per rank, taken in turn: 4 x 98 MB of inputs (and 4 x ~0.6 GB of point
+    # records in the two workspaces) do not stay in the 256 MB Infinity Cache from one step to the next
+    R = max(1, args.rotate)
+    batches = []
+    for b in range(R):
+        fr = make_frames(args.workload, args.batch, seed0=(rank * R + b) * stride)
+        batches.append(dict(frames=fr, poses=lay._poses(fr["position"], fr["yaw"], fr["elevation"]),
+                            depth=fr["depth"].to(dev).reshape(args.batch, H, W).contiguous(),
+                            label=fr["semantic"].to(dev).contiguous()))
+    frames = batches[0]["frames"]
     sequential = args.mode == "sequential"
 
     from mass_amd import _lib
     from mass_amd.utils.projection import fuse_frames, FusePipeline
 
     pipe = None if args.no_pipeline else FusePipeline(dev)
+    counter = [0]
 
     def step():
+        bt = batches[counter[0] % R]
+        counter[0] += 1
         if pipe is None:
-            fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, label, lay.data,
+            fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, bt["poses"], bt["depth"], bt["label"], lay.data,
                         interpolation_weight=lay.interpolation_weight, sequential=sequential, workspace=lay._workspace)
         else:       # stages this step's batch on the side stream, commits the previous step's
-            pipe.submit(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, label, lay.data,
+            pipe.submit(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, bt["poses"], bt["depth"], bt["label"], lay.data,
                         interpolation_weight=lay.interpolation_weight, sequential=sequential)
 
     def drain():
@@ -446,14 +628,16 @@ def run_rank(args):
 
     wall_max = D.max_over_ranks(wall)
 
-    # untimed, informational: the tile kernel with nothing beside it (three one-call steps)
+    # untimed, informational: the tile kernel with nothing beside it (one-call steps)
+    kernel_name = last_mode(lay, args.batch, pipe.ws[0] if pipe is not None else None) if sequential else "fuse_dense_kernel (merged: one group)"
     alone_ms = None
     if pipe is not None:
         _lib.check(_lib.lib.mf_profile_enable(1))
-        for _ in range(4):
-            fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, label, lay.data,
+        for k in range(4):
+            bt = batches[k % R]
+            fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, bt["poses"], bt["depth"], bt["label"], lay.data,
                         interpolation_weight=lay.interpolation_weight, sequential=sequential, workspace=lay._workspace)
-            torch.cuda.synchronize()       # this workspace's density words reach the host before the next call
+            torch.cuda.synchronize()
         one = np.zeros((4, 5), np.float32)
         for k in range(4):
             _lib.check(_lib.lib.mf_profile_read(k, one[k].ctypes.data))
@@ -461,15 +645,24 @@ def run_rank(args):
         alone_ms = float(one[2:, 3].mean())
 
     # ---- bytes one launch has to move: inputs + union of the touched voxels, read + written once ----
-    T, valid_pts, union = footprints(lay, poses, depth)
+    # (per resident batch; a step's figures are the means over the batches the steps take in turn)
+    T, valid_pts, unions = [], 0, []
+    for bt in batches:
+        Tb, vb, ub = footprints(lay, bt["poses"], bt["depth"])
+        T += Tb
+        valid_pts += vb
+        unions.append(ub)
+    valid_pts /= R
+    union = float(np.mean(unions))
     input_bytes = args.batch * H * W * (4 + 1)
     tile_bytes = union * C * 4 * 2
-    per_frame_model = sum(H * W * (4 + 1) + Tf * C * 4 * 2 for Tf in T)       # SURVEY 8(d), informational
+    per_frame_model = sum(H * W * (4 + 1) + Tf * C * 4 * 2 for Tf in T) / R       # SURVEY 8(d), informational
     # the one data collective of the run: SUM all-reduce of the per-rank counters (RCCL)
     metrics = D.reduce_metrics(dict(frames=args.batch * args.steps, valid_points=valid_pts * args.steps,
-                                    touched_voxels=sum(T) * args.steps, union_voxels=union,
+                                    touched_voxels=sum(T) / R * args.steps, union_voxels=union,
                                     map_abs_sum=float(lay.data.abs().sum(dtype=torch.float64))))
 
+    copy_gbps = copy_bandwidth(dev) if rank == 0 else None
     if rank == 0:
         frames_total = args.batch * args.steps * world
         ms_per_step = wall_max / args.steps * 1e3
@@ -488,15 +681,17 @@ def run_rank(args):
                                    f"fp32 map at 0.05 m, distribution {dist_name}, {args.mode} blend"
                                    f"{' (= %d layer.update calls)' % args.batch if sequential else ''}, one map per GPU",
                        "frames_per_step": args.batch, "map": [MAP, MAP, MAP, C], "mode": args.mode,
+                       "resident_batches": R,
                        "issue": ("one mf_fuse_frames call per step" if args.no_pipeline else
                                  "steps pipelined: mf_fuse_frames_stage of step k+1 (bucketing, side stream) overlaps "
                                  "mf_fuse_frames_commit of step k (tile kernels, in order); all K steps complete inside "
                                  "the timed region")},
             "roofline": {"bound": "hbm",
-                         "kernel": "fuse_tiles_kernel" if args.workload == "distA" else
-                                   "fuse_dense_kernel (picked from the second call on: the previous call found the scene dense)",
+                         "kernel": kernel_name + " (picked on the device from the call's point density)",
                          "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "measured_copy_GBps": copy_gbps, "frac_vs_copy": achieved / copy_gbps,
+                         "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": tile_bytes, "kernel_ms": fuse_ms,
                          "kernel_ms_unoverlapped": alone_ms,
@@ -529,18 +724,22 @@ def run_rank(args):
             cb, ref_layer, n_ref = cpu_baseline(frames, args.cpu_frames)
             out["cpu_baseline"] = cb
             if sequential:
-                out["parity"] = parity_vs_oracle(lay_kw, frames, n_ref, ref_layer, dev)
+                out["parity"] = parity_vs_oracle(lay_kw, frames, n_ref, ref_layer, dev, pipe is not None)
             del ref_layer
         if world == 1 and not args.no_extras:
             del lay
             torch.cuda.empty_cache()
-            fa = frames if args.workload == "distA" else make_frames("distA", args.batch, 0)
+            poses, depth, label = batches[0]["poses"], batches[0]["depth"], batches[0]["label"]
+            fa = frames
             if args.workload != "distA":
+                fa = make_frames("distA", args.batch, 0)
                 probe = SemanticProjectionLayer(**lay_kw).to(dev)
                 poses = probe._poses(fa["position"], fa["yaw"], fa["elevation"])
                 del probe
                 depth = fa["depth"].to(dev).reshape(args.batch, H, W).contiguous()
                 label = fa["semantic"].to(dev).contiguous()
+            del batches[1:]
+            torch.cuda.empty_cache()
             out["other_workloads"] = extra_workloads(lay_kw, dev, fa, poses, depth, label)
         print(json.dumps(out), flush=True)
     if world > 1:

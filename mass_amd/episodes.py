@@ -75,3 +75,88 @@ def shard_episodes(n_episodes, rank, world_size):
     """Episode e runs on rank e mod world_size (the reference slices tasks the
     same way with --start-task/--every-tasks, agent.py:154-155)."""
     return [e for e in range(n_episodes) if e % world_size == rank]
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE configs[4]: an episode = a walkthrough map and an unshuffle map of the same room, 300 room
+# frames each (SURVEY 8(d) config 5; the reference's phases: /root/reference/agent.py:314-415), then
+# predict_scene_differences (agent.py:435-444).  Between the phases one "object" has moved.
+# ----------------------------------------------------------------------------------------------
+OBJECT_CLASSES = (41, 47, 52)          # classes of the three box-shaped objects of a synthetic episode
+MOVED_CLASS = 47
+
+
+def episode_objects(episode, phase):
+    """Centres of the episode's objects (on the walls of the 6 x 6 x 3 m room); MOVED_CLASS sits somewhere
+    else in phase 1 (unshuffle) than in phase 0 (walkthrough)."""
+    g = torch.Generator().manual_seed(7919 * episode + 13)
+    u = torch.rand(4, generator=g)
+    fixed_a = (2.95, float(-1.5 + 3.0 * u[0]), -0.8)
+    fixed_b = (float(-1.5 + 3.0 * u[1]), -2.95, -0.6)
+    x0 = float(-2.0 + 1.0 * u[2])
+    moved = (x0, 2.95, -0.9) if phase == 0 else (x0 + 2.2, 2.95, -0.9)
+    return {OBJECT_CLASSES[0]: fixed_a, OBJECT_CLASSES[2]: fixed_b, MOVED_CLASS: moved}
+
+
+def episode_trajectory(episode, phase, n, height=480, width=640, num_classes=NUM_CLASSES, half_size=0.45):
+    """room_trajectory(seed = 1000 * episode + phase) with the episode's objects painted into the class-id
+    images (a pixel whose hit point lies within `half_size` of an object's centre carries its class)."""
+    tr = room_trajectory(n, height, width, seed=1000 * episode + phase, num_classes=num_classes)
+    focal = height / 2.0 / np.tan(np.radians(90.0) / 2.0)
+    cam = project_camera_rays(height, width, focal, focal)
+    sem = tr["semantic"].clone()
+    objects = episode_objects(episode, phase)
+    for t in range(n):
+        eye = spherical_to_cartesian(tr["yaw"][t], tr["elevation"][t])
+        up = spherical_to_cartesian(tr["yaw"][t], tr["elevation"][t] + np.pi / 2)
+        q = (cam.unsqueeze(-2) * rotation_matrix(eye, up)).sum(-1)
+        hit = tr["position"][t] + q * tr["depth"][t]
+        # background classes stay away from the object classes
+        bg = sem[t]
+        for cls in OBJECT_CLASSES:
+            bg[bg == cls] = 0
+        for cls, centre in objects.items():
+            d = (hit - torch.tensor(centre)).abs()
+            bg[(d[..., 0] < half_size) & (d[..., 1] < half_size) & (d[..., 2] < half_size)] = cls
+    tr["semantic"] = sem
+    return tr
+
+
+def prepare_episode(episode, device, n_frames=300, height=480, width=640, num_classes=NUM_CLASSES):
+    """The episode's two trajectories with depth and class ids resident on `device` (poses stay on the host:
+    the layers do the pose trigonometry there, like the reference)."""
+    phases = []
+    for phase in range(2):
+        tr = episode_trajectory(episode, phase, n_frames, height, width, num_classes)
+        phases.append(dict(position=tr["position"], yaw=tr["yaw"], elevation=tr["elevation"],
+                           depth=tr["depth"].to(device), semantic=tr["semantic"].to(device)))
+    return dict(episode=episode, n_frames=n_frames, phases=phases)
+
+
+def make_episode_layers(device, height=480, width=640, map_size=256, num_classes=NUM_CLASSES, grid_resolution=0.05):
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    kw = dict(camera_height=height, camera_width=width, map_height=map_size, map_width=map_size, map_depth=map_size,
+              feature_size=num_classes, grid_resolution=grid_resolution)
+    return [SemanticProjectionLayer(**kw).to(device) for _ in range(2)]
+
+
+def run_episode(prepared, layers, batch=64):
+    """One synthetic episode: both phases' frames fused into their semantic maps in sequential batches
+    (= per-frame layer.update() calls), then predict_scene_differences over the object classes.
+    Returns the episode's counters (what the ranks all-reduce at the end of a multi-GPU run)."""
+    from mass_amd.utils.experimentation import predict_scene_differences
+    n_frames, frames = prepared["n_frames"], 0
+    for tr, lay in zip(prepared["phases"], layers):
+        lay.reset()
+        for b0 in range(0, n_frames, batch):
+            sl = slice(b0, min(b0 + batch, n_frames))
+            lay.update_batch(dict(position=tr["position"][sl], yaw=tr["yaw"][sl], elevation=tr["elevation"][sl],
+                                  depth=tr["depth"][sl], semantic=tr["semantic"][sl]), sequential=True, validate="defer")
+            frames += sl.stop - sl.start
+        lay.check_labels()
+    obj, goals0, goals1 = predict_scene_differences(layers[0], layers[1], None, None, set(), list(OBJECT_CLASSES),
+                                                    confidence_threshold=0.0, contour_padding=0, distance_threshold=0.5)
+    shift = float((goals1[0] - goals0[0]).norm()) if goals0 else 0.0
+    return dict(episodes=1, frames=frames, moved_found=int(obj == MOVED_CLASS), n_matches=len(goals0), shift_m=shift,
+                occupied_voxels=float(sum(int((l.data != 0).any(-1).sum()) for l in layers)),
+                map_abs_sum=float(sum(float(l.data.abs().sum(dtype=torch.float64)) for l in layers)))
