@@ -164,32 +164,38 @@ def cpu_baseline(frames, per_rep, reps=3):
         total += dt
         if r > 0:
             rates.append(per_rep / dt)
-    # single thread, on a copy of the map (so that the parity map stays the one after n frames)
-    single = None
+    used = orc.last_threads()          # 1 on unrelated frames: memory bound, the port takes one thread there (see massref.c)
+    # the other thread count, on a copy of the map (so that the parity map stays the one after n frames)
+    other, other_threads = None, (threads if used == 1 else 1)
     n1 = min(3, max(frames["depth"].shape[0] - n, 0))
-    if n1 > 0:
+    if n1 > 0 and other_threads != used:
         lay1 = orc.RefProjectionLayer(camera_height=H, camera_width=W, map_height=MAP, map_width=MAP, map_depth=MAP,
                                       feature_size=C, grid_resolution=0.05)
         lay1.data.copy_(lay.data)
         batch = [obs(f) for f in range(n, n + n1)]
-        orc.set_threads(1)
+        orc.force_threads(True)
+        orc.set_threads(other_threads)
         try:
             t0 = time.perf_counter()
             for o in batch:
                 lay1.update(o)
-            single = n1 / (time.perf_counter() - t0)
+            other = n1 / (time.perf_counter() - t0)
         finally:
+            orc.force_threads(False)
             orc.set_threads(threads)
         del lay1
-    rec = dict(value=statistics.median(rates), unit="frames/s", cores=threads, kind="port",
-               reps=reps, rates=[round(x, 4) for x in rates], single_thread_frames_per_s=single,
+    rec = dict(value=statistics.median(rates), unit="frames/s", cores=used, kind="port",
+               reps=reps, rates=[round(x, 4) for x in rates],
+               other_thread_count=dict(threads=other_threads, frames_per_s=other),
                cpu_model=cpu_model(), host_cpus=os.cpu_count(),
                torch_threads=torch.get_num_threads(), torch=torch.__version__,
                sample=f"frames {per_rep}..{n - 1} of rank 0's batch through oracle/massref.c (bin_rays + "
                       f"update_feature_map on one-hot fp32 features as the reference builds them), sequential "
                       f"onto one {MAP}^3 x {C} map: 1 warm + {reps} timed repetitions of {per_rep} frames, median; "
-                      f"{total:.1f} s of CPU work on {threads} threads (OpenMP over the touched voxels, bit-identical to "
-                      f"one thread); single_thread_frames_per_s: the next {n1} frames on one thread",
+                      f"{total:.1f} s of CPU work on {used} thread(s) (the port threads its blend loop over the touched voxels, "
+                      f"bit-identically, when voxels receive many contributions each; on unrelated frames that loop is "
+                      f"memory bound and it takes one thread); other_thread_count: the next {n1} frames forced onto "
+                      f"{other_threads} thread(s)",
                reference_in_build_container="0.52 frames/s (the reference's own torch CPU path, 8 threads, "
                                             "256^3 x 54; SURVEY section 6)")
     return rec, lay, n

@@ -43,7 +43,8 @@ _lib = None
 
 def _default_threads():
     """Threads of the blend loop (bit-identical results for any count, see massref.c): MASSREF_THREADS, else
-    the CPUs this process may use, at most 32."""
+    the CPUs this process may use, at most 8 (more threads than a container's CPU share make it slower: every
+    thread walks all contributions and only the per-voxel work is divided)."""
     env = os.environ.get("MASSREF_THREADS")
     if env:
         return max(1, int(env))
@@ -51,7 +52,7 @@ def _default_threads():
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 32))
+    return max(1, min(n, 8))
 
 
 def set_threads(n):
@@ -60,6 +61,16 @@ def set_threads(n):
 
 def get_threads():
     return lib().ref_get_threads()
+
+
+def force_threads(on):
+    """Run the blend loop on the set number of threads whatever the scene (by default it takes one thread when the
+    voxels receive few contributions each: such frames are memory bound and threads make them slower)."""
+    lib().ref_force_threads(1 if on else 0)
+
+
+def last_threads():
+    return lib().ref_last_threads()
 
 
 def lib():
@@ -85,6 +96,9 @@ def lib():
         L.ref_set_threads.argtypes = [ctypes.c_int]
         L.ref_set_threads.restype = None
         L.ref_get_threads.restype = ctypes.c_int
+        L.ref_force_threads.argtypes = [ctypes.c_int]
+        L.ref_force_threads.restype = None
+        L.ref_last_threads.restype = ctypes.c_int
         L.ref_set_threads(_default_threads())
         _lib = L
     return _lib

@@ -166,19 +166,22 @@ def test_threaded_blend_is_bit_identical_to_the_single_thread():
               grid_resolution=0.1)
     init = torch.rand(40, 40, 24, 7, generator=g)
     obs = [dict(position=0.2 * torch.randn(3, generator=g), yaw=float(6.28 * torch.rand((), generator=g)),
-                elevation=-0.4, depth=0.3 + 1.2 * torch.rand(60, 80, 1, generator=g),
+                elevation=-0.4, depth=0.9 + 0.1 * torch.rand(60, 80, 1, generator=g),
                 features=torch.rand(60, 80, 7, generator=g)) for _ in range(3)]
     before = orc.get_threads()
     outs = []
     try:
+        orc.force_threads(True)
         for n in (1, 3, 8):
             orc.set_threads(n)
             lay = orc.RefProjectionLayer(**kw)
             lay.data.copy_(init)
             for o in obs:
                 lay.update(o)
+            assert orc.last_threads() == n
             outs.append(lay.data.clone())
     finally:
+        orc.force_threads(False)
         orc.set_threads(before)
     assert bool((outs[0] != init).any())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
