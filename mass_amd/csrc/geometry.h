@@ -14,31 +14,41 @@ namespace mf {
 // torch.bucketize(p, edges, right=True): number of edges <= p, NaN -> n
 // (ATen upper bound: `if (!(mid_val > val)) start = mid + 1`).  The edges come
 // from torch.arange on the host and are data, not a formula, so
-// the uniform-grid estimate below is only a starting guess that is then
-// verified against the real edges; a bad guess falls back to bisection.
+// the uniform-grid estimate below is only a starting guess: the four edges
+// around it are fetched together and counted (no loop, no branch), which is
+// the answer whenever it lies inside that window and the window's ends prove
+// it (the guess is off by one at most for edges that come from arange); any
+// other case, and any grid of fewer than four edges, falls back to bisection.
+__device__ __forceinline__ int upper_bound_bisect(const float *__restrict__ b, int n, float p)
+{
+    int start = 0, end = n;
+    while (start < end) {
+        const int mid = start + ((end - start) >> 1);
+        if (!(b[mid] > p)) start = mid + 1; else end = mid;
+    }
+    return start;
+}
+
 __device__ __forceinline__ int upper_bound_edges(const float *__restrict__ b, int n, float p)
 {
     if (!(p == p)) return n;
+    if (n < 4) return upper_bound_bisect(b, n, p);
     const float b0 = b[0];
     const float step = b[1] - b0;
     const float t = (p - b0) * __builtin_amdgcn_rcpf(step);   // a guess only: verified against the edges below
-    int c;
-    if (!(t >= 0.0f)) c = 0;
-    else if (t >= (float)n) c = n;
-    else c = (int)t + 1;
-    int steps = 0;
-    bool ok = true;
-    while (c < n && !(b[c] > p)) { ++c; if (++steps > 3) { ok = false; break; } }
-    if (ok) while (c > 0 && b[c - 1] > p) { --c; if (++steps > 6) { ok = false; break; } }
-    if (!ok) {
-        int start = 0, end = n;
-        while (start < end) {
-            const int mid = start + ((end - start) >> 1);
-            if (!(b[mid] > p)) start = mid + 1; else end = mid;
-        }
-        c = start;
-    }
-    return c;
+    int g;                                                     // guess of the answer
+    if (!(t >= 0.0f)) g = 0;
+    else if (t >= (float)n) g = n;
+    else g = (int)t + 1;
+    int lo = g - 2;                                            // window of four edges lo .. lo + 3 around the guess
+    lo = lo < 0 ? 0 : (lo > n - 4 ? n - 4 : lo);
+    const float e0 = b[lo], e1 = b[lo + 1], e2 = b[lo + 2], e3 = b[lo + 3];
+    const int cnt = (int)(e0 <= p) + (int)(e1 <= p) + (int)(e2 <= p) + (int)(e3 <= p);   // ascending edges: a prefix
+    // the count is the answer if the edge before the window is known to be <= p (there is none, or one inside the
+    // window already is) and the edge after it is known to be > p (there is none, or one inside the window already is)
+    const bool ok = (cnt > 0 || lo == 0) && (cnt < 4 || lo + 4 == n);
+    if (ok) return lo + cnt;
+    return upper_bound_bisect(b, n, p);
 }
 
 struct Bins {
