@@ -22,7 +22,14 @@
 //   3. scatter   : writes the 20-byte point record of every (pixel, tile) pair into its bucket
 //                  slot (slot = bucket base + LDS-local rank);
 //   4. tile kernel, one of
-//        fuse_tiles_kernel   sparse frames, dense fp32 features, any tile shape: persistent
+//        fuse_cells_kernel   sequential frames of class ids / ones, sparse (a batch of unrelated frames): all
+//                  frames of a 4 x 4 x 8 tile at once through compact (voxel, frame) cells, integer sums
+//                  only, three 256-thread workgroups per CU (see there);
+//        fuse_dense_kernel   the same feature kinds, real scenes: everything accumulated as integers on
+//                  4 x 4 x 8 tiles, suffix form of the unrolled blend (see there);
+//                  (both read tile-local "meta" records, make_meta_record; tile_list_kernel picks one of
+//                  the two from the call's own point density: no state is kept between calls)
+//        fuse_tiles_kernel   dense fp32 features, blend weights outside [0, 1], any tile shape: persistent
 //                  workgroups walk the tile list (ticket counter; the next tile's ticket, id,
 //                  offsets and first records are fetched one tile ahead).  The tile's old map
 //                  values are preloaded into LDS by LDS-DMA while pass 1 runs; frames are taken
@@ -30,15 +37,14 @@
 //                  (ds_add_f32 is 29x slower than ds_add_u32 on gfx950), pass 2 turns them into
 //                  k_f = g_f / s_f per voxel, pass 3 adds w^2 k_f feat (compare-and-swap, float
 //                  atomic only on a lost race); the final pass writes s * D row by row;
-//        fuse_dense_kernel   real scenes (class ids / ones): everything accumulated as integers on
-//                  4 x 4 x 8 tiles, suffix form of the unrolled blend (see there);
 //        fuse_single_kernel / fuse_single_dense_kernel   single-group calls: one pass, integer sums.
 // No global float atomics are used (guide: ~1.3 TB/s, 17x slower when scattered); HBM sees each
 // tile once per call, coalesced along z.
 //
-// Tuning / diagnostics, all off by default: MF_TILE="s0 s1 s2 threads [gc]" overrides the tile
-// shape, MF_DENSE=0/1 pins the tile shape of multi-frame calls (MF_DENSE_FORCE also the kernel),
-// MF_DENSE_GC / MF_DENSE_NT its chunk and workgroup size, MF_BLOCKS caps the workgroups,
+// Tuning / diagnostics, all off by default and range-checked (env_int): MF_TILE="s0 s1 s2 threads [gc]"
+// overrides the tile shape of fuse_tiles_kernel, MF_DENSE=0 keeps calls off the 4 x 4 x 8 integer kernels,
+// MF_DENSE_FORCE / MF_CELLS_FORCE give every eligible call to that kernel, MF_CELLS=0 keeps the cells kernel out,
+// MF_DENSE_GC / MF_DENSE_NT / MF_CELLS_PER_CU size them, MF_BLOCKS caps the workgroups,
 // MF_STAMPS=1 prints the share of each phase of the tile kernel (dev builds of bench runs).
 #include <cstdlib>
 #include <mutex>
