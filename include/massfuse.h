@@ -157,6 +157,23 @@ MF_API size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int
 MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
                    int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
 
+/* One observation onto several maps: what the reference's agent does per simulator step,
+ * `for name in update_map: self.feature_maps[name].update(observations)`
+ * (navigation_policy.py:164-171, maps built at agent.py:107-111).  grids[m] / frames[m] /
+ * interpolation_weights[m] / workspaces[m] describe map m exactly as a mf_fuse_frames call would
+ * (its own map buffer, channels, features, label_status, blend weight, workspace); the maps share
+ * their voxel grid (sizes; the edges of grids[0] are the ones used - the caller passes maps whose
+ * edges are equal) and the frames their rays, poses and depth.  n_maps <= 4.
+ * The result on every map is that of its own mf_fuse_frames call, bit for bit.  A single group
+ * (one frame, or MF_MODE_MERGED) is bucketed ONCE - the points, their tiles and records do not
+ * depend on the features - and the maps' tile kernels run side by side on streams the library
+ * keeps per host thread, forked after what `stream` holds at the call and joined into it before
+ * the call returns; other calls are issued map after map.  A class id out of range on one map
+ * (its label_status set) leaves that map untouched and the others updated, as in the loop. */
+MF_API int mf_fuse_frame_maps(const mf_grid *grids, const mf_frames *frames, const float *interpolation_weights,
+                       int32_t n_maps, int32_t mode, void *const *workspaces, const size_t *workspace_bytes,
+                       void *stream);
+
 /* The same update in two halves, for callers that fuse batch after batch: `stage` buckets the
  * frames' points into the workspace (unproject, bin, count, scatter: the map is not read), `commit`
  * applies a staged workspace to the map.  Staging batch k+1 on a second stream while batch k is

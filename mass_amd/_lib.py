@@ -21,7 +21,8 @@ MODE_SEQUENTIAL, MODE_MERGED = 0, 1
 METRIC_L2, METRIC_L2_GEMM, METRIC_COSINE = 0, 1, 2
 MAX_FRAMES_PER_CALL = 256
 ABI_VERSION = 4
-MODE_TILES, MODE_DENSE, MODE_CELLS = 0, 2, 3          # mf_fuse_last_mode
+MODE_TILES, MODE_DENSE, MODE_CELLS = 0, 2, 3
+MAX_MAPS_PER_CALL = 4          # mf_fuse_frame_maps          # mf_fuse_last_mode
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_float, ctypes.c_size_t)
@@ -71,6 +72,8 @@ SIGNATURES = {
                                             c_void_p, c_size_t, c_void_p]),
     "mf_fuse_frames_commit": (ctypes.c_int, [ctypes.POINTER(MfGrid), ctypes.POINTER(MfFrames), c_float, c_int32,
                                              c_void_p, c_size_t, c_void_p]),
+    "mf_fuse_frame_maps": (ctypes.c_int, [ctypes.POINTER(MfGrid), ctypes.POINTER(MfFrames), ctypes.POINTER(c_float), c_int32,
+                                          c_int32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),
     "mf_update_feature_map": (ctypes.c_int, [ctypes.POINTER(MfGrid), c_int64, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float,
                                              c_void_p, c_size_t, c_void_p]),

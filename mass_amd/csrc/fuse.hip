@@ -49,6 +49,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 #include "common.h"
 #include "geometry.h"
 
@@ -91,7 +92,17 @@ struct FuseParams {
     uint4 *rec;
     uint32_t *aux;
     uint4 *pts;                // [n_points] (front end 0) the binned pixels, written by count_kernel for scatter_kernel
+    // further maps updated from the same frames (mf_fuse_frame_maps): they share the records, each has its own word per record
+    int n_extra;
+    struct ExtraMap {
+        const void *feat;
+        int feat_kind, C, fh, fw, rep_y, rep_x;
+        uint32_t *aux;         // [cap] class id / feature pixel per record (NULL: ones)
+        int *label_status;     // optional, as above
+        int *abort;            // its tile_list_kernel lists nothing when this word is set
+    } extra[3];
 };
+constexpr int MAX_EXTRA_MAPS = 3;
 
 // What the tile kernel needs (a subset: fewer scalar registers held across its loop).
 struct TileParams {
@@ -340,6 +351,16 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
             *P.label_status = 1;                        // reported to the host ...
             P.ticket[ABORT_SLOT] = 1;                   // ... and the rest of the pipeline is called off
         }
+        if (FRONT == 0) {
+            for (int m = 0; m < P.n_extra; ++m) {       // class ids of the further maps: every pixel is looked at, as above
+                const FuseParams::ExtraMap &E = P.extra[m];
+                if (!E.label_status || E.feat_kind < MF_FEAT_LABEL_U8 || E.feat_kind > MF_FEAT_LABEL_I64) continue;
+                const int pix = (int)(idx - (long long)blockIdx.y * (P.H * P.W));
+                const int y = pix / P.W, x = pix - y * P.W;
+                const long long fi = ((long long)blockIdx.y * E.fh + y / E.rep_y) * E.fw + x / E.rep_x;
+                if (read_label(E.feat, E.feat_kind, fi) >= (uint32_t)E.C) { *E.label_status = 1; *E.abort = 1; }
+            }
+        }
         if (FRONT == 0) {                               // scatter_kernel takes the binned pixel from here (no second unprojection)
             uint4 r = make_record(pt);
             if (!ok) r.y = 0xffffffffu;                // no ratio in [0, 1] has these low 30 bits
@@ -368,6 +389,7 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
     __syncthreads();
     const long long idx = point_index<FRONT>(P, BIN_THREADS);
     Point pt; uint32_t aux = 0;
+    uint32_t xaux[MAX_EXTRA_MAPS] = {0u, 0u, 0u};
     uint32_t keys[8];
     int slot[8], rank[8];
     int n = 0;
@@ -386,6 +408,14 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
                 const int y = pix / P.W, x = pix - y * P.W;
                 const long long fi = ((long long)blockIdx.y * P.fh + y / P.rep_y) * P.fw + x / P.rep_x;
                 aux = P.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)fi : read_label(P.feat, P.feat_kind, fi);
+            }
+            for (int m = 0; m < P.n_extra; ++m) {
+                const FuseParams::ExtraMap &E = P.extra[m];
+                if (!E.aux) continue;
+                const int pix = (int)(idx - (long long)blockIdx.y * (P.H * P.W));
+                const int y = pix / P.W, x = pix - y * P.W;
+                const long long fi = ((long long)blockIdx.y * E.fh + y / E.rep_y) * E.fw + x / E.rep_x;
+                xaux[m] = E.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)fi : read_label(E.feat, E.feat_kind, fi);
             }
         }
     } else {
@@ -419,6 +449,9 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
                 const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
                 P.rec[pos] = r;
                 if (P.feat_kind != MF_FEAT_ONES) P.aux[pos] = aux;
+                if (FRONT == 0)
+                    for (int m = 0; m < P.n_extra; ++m)
+                        if (P.extra[m].aux) P.extra[m].aux[pos] = xaux[m];
             }
         }
     }
@@ -508,6 +541,7 @@ constexpr int MODE_SLOT = ABORT_SLOT + 5;       // which tile kernel takes the c
 constexpr int HINT_SLOT = ABORT_SLOT + 6;       // [2] records listed, non-empty buckets x tile voxels / 2 (diagnostics)
 constexpr int TICKET_DENSE = ABORT_SLOT + 8;    // work counter of fuse_dense_kernel (ticket[0] is fuse_tiles_kernel's)
 constexpr int TICKET_CELLS = ABORT_SLOT + 9;    // work counter of fuse_cells_kernel
+constexpr int ABORT_MAPS = 32;                  // [MAX_EXTRA_MAPS] abort words of the further maps of a mf_fuse_frame_maps call
 constexpr int MODE_TILES = 0, MODE_DENSE = 2, MODE_CELLS = 3;
 constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
@@ -518,14 +552,17 @@ __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ 
                                                         int n_tiles, int G, int *ticket, int *active,
                                                         int split_min, int split_part, int split_slots, int *items,
                                                         int min_mean, int first_ticket, int dense_tv,
-                                                        int first_ticket_dense, int first_ticket_cells)
+                                                        int first_ticket_dense, int first_ticket_cells,
+                                                        const int *abort /* a class id was out of range */,
+                                                        const int *nonempty /* buckets with entries (scan_apply_kernel) */,
+                                                        int after_scatter /* cursor[k] is the END of bucket k (scatter_kernel has run) */)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
         // Density of the call: records per non-empty (tile, frame) bucket and tile voxel.  Half a record per
         // voxel and frame or more is a real scene (a batch of unrelated frames has 0.03): the all-integer
         // tile kernel takes it when the call was bucketed on its tiles (dense_tv = their voxel count, else 0).
-        const long long total = cursor[n_tiles * G], half = (long long)ticket[SPLIT_NONEMPTY] * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
+        const long long total = cursor[n_tiles * G], half = (long long)*nonempty * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
         // bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is, bits 22 / 23: forced (dev / tests),
         // bit 24: the records are tile-local (meta format): only these two kernels read them
         const bool dense_ok = dense_tv & (1 << 20), cells_ok = dense_tv & (1 << 21);
@@ -539,13 +576,13 @@ __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ 
         ticket[TICKET_CELLS] = first_ticket_cells;
     }
     int n = 0;
-    if (ticket[ABORT_SLOT]) return;                 // a class id was out of range: no tile is listed, the map stays as it is
-    if (t < n_tiles) n = cursor[(t + 1) * G] - cursor[t * G];
+    if (*abort) return;                             // a class id was out of range: no tile is listed, the map stays as it is
+    if (t < n_tiles) n = after_scatter ? cursor[(t + 1) * G - 1] - (t > 0 ? cursor[t * G - 1] : 0) : cursor[(t + 1) * G] - cursor[t * G];
     // A call whose tiles are sparse on average (a synthetic frame of unrelated depths: ~40 records per
     // tile) is better off in the tile kernel, which spends less per tile; a real frame (hundreds to
     // thousands of records per tile) goes to the single-pass kernel.  The whole call goes one way.
     // (With ones features the single-pass kernel has no per-class state and wins on both.)
-    if (split_min > 0 && (long long)cursor[n_tiles * G] < (long long)ticket[SPLIT_NONEMPTY] * min_mean) split_min = 0;
+    if (split_min > 0 && (long long)cursor[n_tiles * G] < (long long)*nonempty * min_mean) split_min = 0;
     if (split_min > 0 && n > 0) {                   // single-pass kernel: every tile is an item, a big one several
         int nparts = 1, slot = 0xffff;
         if (n > split_min) {
@@ -2697,11 +2734,26 @@ static void prof_mark(int i, hipStream_t st)
     if (g_profile && g_ev_ready && slot < PROF_CALLS) (void)hipEventRecord(g_ev[slot][i], st);
 }
 
+// Several maps updated from the same frames (mf_fuse_frame_maps): the first map's call buckets the points for all
+// of them (role 0: it also fills their per-record words and checks their class ids), a further map (role 1) takes
+// cursor and records from the first one's workspace, lists its tiles in its own and runs its tile kernels, on a
+// stream of its own, behind the first map's scatter (`scattered`).
+struct MultiCtx {
+    int role;
+    hipEvent_t scattered;      // recorded behind the first map's scatter_kernel
+    // role 1
+    int *cursor;
+    uint4 *rec;
+    const int *nonempty;
+    const int *abort;
+    int s0, s1, s2;            // the tile shape the records were bucketed on
+};
+
 template <int FRONT>
 // phase: 1 = stage (bucket the points: memset, count, scan, tile list, scatter; the map is not touched),
 //        2 = commit (the tile kernels, on a workspace staged with the same arguments), 3 = both
 static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, size_t workspace_bytes, hipStream_t st,
-                        int phase = 3)
+                        int phase = 3, const MultiCtx *mc = nullptr)
 {
     if (P.G < 1 || P.G > MAX_GROUPS)
         return fail(MF_ERR_INVALID, "at most %d sequential frames per call, got %d", MAX_GROUPS, P.G);
@@ -2729,6 +2781,11 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     P.aux = (uint32_t *)(ws + L.aux);
     P.n_tiles = P.nt0 * P.nt1 * P.nt2;
     P.n_keys = L.n_keys;
+    const bool follower = mc && mc->role == 1;
+    if (follower) {
+        if (P.s0 != mc->s0 || P.s1 != mc->s1 || P.s2 != mc->s2) return fail(MF_ERR_INVALID, "maps of one call need one tile shape");
+        P.cursor = mc->cursor; P.rec = mc->rec;
+    }
 
     // single-pass path: one group, class ids or ones (dense features keep the tile kernel)
     const bool dense = P.feat_kind == MF_FEAT_DENSE_F32;
@@ -2794,7 +2851,26 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (blocks_cap > 0 && blocks_cells > blocks_cap) blocks_cells = blocks_cap;
     if (blocks_cells > P.n_tiles) blocks_cells = P.n_tiles;
 
-    if (phase & 1) {
+    const int list_dense_tv = (use_dense || use_cells ? 1 << sv : 0) | (use_dense ? 1 << 20 : 0) | (use_cells ? 1 << 21 : 0) |
+                              (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0) |
+                              (P.meta ? 1 << 24 : 0);
+    if (follower) {
+        // own counters and split scratch, own feature range, own tile list from the shared offsets; then behind the scatter
+        MF_HIP_CHECK(hipMemsetAsync(ws + L.ticket, 0, (single ? L.active : L.slot_count) - L.ticket, st));
+        if (single && dense) {
+            const long long nf = (long long)P.n_frames * P.fh * P.fw * P.C;
+            hipLaunchKernelGGL(feat_absmax_kernel, dim3((unsigned)((nf + 256 * 16 - 1) / (256 * 16) > 1024 ? 1024 : (nf + 256 * 16 - 1) / (256 * 16))),
+                               dim3(256), 0, st, (const float *)P.feat, nf, P.ticket + FEAT_ABSMAX);
+            MF_LAUNCH_CHECK("feat_absmax_kernel");
+        }
+        // (scatter_kernel turns the bucket offsets into bucket ends as it goes: the list is made from the ends, behind it)
+        MF_HIP_CHECK(hipStreamWaitEvent(st, mc->scattered, 0));
+        hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
+                           P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
+                           (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks, list_dense_tv,
+                           4 * blocks_dense, blocks_cells, mc->abort, mc->nonempty, 1);
+        MF_LAUNCH_CHECK("tile_list_kernel");
+    } else if (phase & 1) {
     prof_mark(0, st);
     // cursor .. ticket (.. split scratch) are contiguous: one memset
     MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, (single ? L.active : L.slot_count) - L.cursor, st));
@@ -2815,15 +2891,13 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     MF_LAUNCH_CHECK("scan_apply_kernel");
     hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
                        P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
-                       (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks,
-                       (use_dense || use_cells ? 1 << sv : 0) | (use_dense ? 1 << 20 : 0) | (use_cells ? 1 << 21 : 0) |
-                           (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0) |
-                           (P.meta ? 1 << 24 : 0),
-                       4 * blocks_dense, blocks_cells);
+                       (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks, list_dense_tv,
+                       4 * blocks_dense, blocks_cells, (const int *)(P.ticket + ABORT_SLOT), (const int *)(P.ticket + SPLIT_NONEMPTY), 0);
     MF_LAUNCH_CHECK("tile_list_kernel");
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
+    if (mc) MF_HIP_CHECK(hipEventRecord(mc->scattered, st));
     prof_mark(3, st);
     if (g_profile && g_ev_ready && g_prof_stages < PROF_CALLS) ++g_prof_stages;
     }
@@ -3060,6 +3134,138 @@ int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpola
     P.G = mode == MF_MODE_SEQUENTIAL ? frames->n_frames : 1;
     P.iw = interpolation_weight;
     return run_pipeline<0>(P, grid, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- several maps from the same frames ----
+// Side streams and events of mf_fuse_frame_maps, per host thread and device (created on first use, kept).
+struct MapStreams {
+    int device = -1;
+    hipStream_t side[MAX_EXTRA_MAPS] = {};
+    hipEvent_t entry = nullptr, scattered = nullptr, done[MAX_EXTRA_MAPS] = {};
+};
+
+static int map_streams(MapStreams *&out)
+{
+    static thread_local std::vector<MapStreams> pool;
+    int dev = 0;
+    MF_HIP_CHECK(hipGetDevice(&dev));
+    for (MapStreams &m : pool)
+        if (m.device == dev) { out = &m; return MF_OK; }
+    MapStreams m;
+    m.device = dev;
+    for (int i = 0; i < MAX_EXTRA_MAPS; ++i) {
+        MF_HIP_CHECK(hipStreamCreateWithFlags(&m.side[i], hipStreamNonBlocking));
+        MF_HIP_CHECK(hipEventCreateWithFlags(&m.done[i], hipEventDisableTiming));
+    }
+    MF_HIP_CHECK(hipEventCreateWithFlags(&m.entry, hipEventDisableTiming));
+    MF_HIP_CHECK(hipEventCreateWithFlags(&m.scattered, hipEventDisableTiming));
+    pool.push_back(m);
+    out = &pool.back();
+    return MF_OK;
+}
+
+int mf_fuse_frame_maps(const mf_grid *grids, const mf_frames *frames, const float *interpolation_weights, int32_t n_maps,
+                       int32_t mode, void *const *workspaces, const size_t *workspace_bytes, void *stream)
+{
+    if (!grids || !frames || !interpolation_weights || !workspaces || !workspace_bytes) return fail(MF_ERR_INVALID, "argument array is NULL");
+    if (n_maps < 1 || n_maps > 1 + MAX_EXTRA_MAPS) return fail(MF_ERR_INVALID, "1 to %d maps per call, got %d", 1 + MAX_EXTRA_MAPS, n_maps);
+    if (mode != MF_MODE_SEQUENTIAL && mode != MF_MODE_MERGED) return fail(MF_ERR_INVALID, "unknown mode %d", mode);
+    for (int m = 0; m < n_maps; ++m) {
+        int rc = check_grid(&grids[m], true);
+        if (rc != MF_OK) return rc;
+        rc = check_frames(&frames[m], grids[m].channels);
+        if (rc != MF_OK) return rc;
+        const mf_grid &g = grids[m], &g0 = grids[0];
+        const mf_frames &f = frames[m], &f0 = frames[0];
+        if (g.size0 != g0.size0 || g.size1 != g0.size1 || g.size2 != g0.size2)
+            return fail(MF_ERR_INVALID, "map %d is %d x %d x %d, map 0 is %d x %d x %d: the maps of one call share their voxel grid",
+                        m, g.size0, g.size1, g.size2, g0.size0, g0.size1, g0.size2);
+        if (f.n_frames != f0.n_frames || f.height != f0.height || f.width != f0.width || f.cam_rays != f0.cam_rays ||
+            f.poses != f0.poses || f.depth != f0.depth || f.min_depth != f0.min_depth || f.max_depth != f0.max_depth)
+            return fail(MF_ERR_INVALID, "frames[%d] differs from frames[0] in more than its features: the maps of one call "
+                        "are updated from the same rays, poses and depth", m);
+        for (int k = 0; k < m; ++k)
+            if (grids[k].map == g.map) return fail(MF_ERR_INVALID, "maps %d and %d are the same buffer", k, m);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int G = mode == MF_MODE_SEQUENTIAL ? frames[0].n_frames : 1;
+    // what is shared is the bucketing of a single group; anything else (and maps whose tiles differ) is the plain loop
+    bool share = n_maps > 1 && G == 1;
+    int s0 = 0, s1 = 0, s2 = 0;
+    Layout L[1 + MAX_EXTRA_MAPS];
+    for (int m = 0; m < n_maps && share; ++m) {
+        int a, b, c, n0, n1, n2;
+        choose_tile(&grids[m], G, false, a, b, c);
+        if (m == 0) { s0 = a; s1 = b; s2 = c; }
+        else if (a != s0 || b != s1 || c != s2) share = false;
+        const long long n_points = (long long)frames[m].n_frames * frames[m].height * frames[m].width;
+        if (share && !make_layout(&grids[m], n_points, G, s0, s1, s2, L[m], n0, n1, n2))
+            return fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets");
+        if (share && (!workspaces[m] || workspace_bytes[m] < L[m].total))
+            return fail(MF_ERR_WORKSPACE, "workspace %d of %zu bytes given, %zu needed", m, workspace_bytes[m], L[m].total);
+        if (share && ((uintptr_t)workspaces[m] & 255) != 0) return fail(MF_ERR_INVALID, "workspace must be 256-byte aligned");
+    }
+    if (!share) {
+        for (int m = 0; m < n_maps; ++m) {
+            const int rc = mf_fuse_frames(&grids[m], &frames[m], interpolation_weights[m], mode, workspaces[m], workspace_bytes[m], stream);
+            if (rc != MF_OK) return rc;
+        }
+        return MF_OK;
+    }
+    MapStreams *ms = nullptr;
+    int rc = map_streams(ms);
+    if (rc != MF_OK) return rc;
+    // the first map's call buckets for all
+    FuseParams P = {};
+    fill_grid(P, &grids[0]);
+    fill_frames(P, &frames[0]);
+    P.G = G;
+    P.iw = interpolation_weights[0];
+    char *ws0 = (char *)workspaces[0];
+    int *ticket0 = (int *)(ws0 + L[0].ticket);
+    P.n_extra = n_maps - 1;
+    for (int m = 1; m < n_maps; ++m) {
+        FuseParams::ExtraMap &E = P.extra[m - 1];
+        const mf_frames &f = frames[m];
+        E.feat = f.feat; E.feat_kind = f.feat_kind; E.C = grids[m].channels;
+        E.fh = f.feat_kind == MF_FEAT_ONES ? f.height : f.feat_height;
+        E.fw = f.feat_kind == MF_FEAT_ONES ? f.width : f.feat_width;
+        E.rep_y = f.height / E.fh; E.rep_x = f.width / E.fw;
+        E.aux = f.feat_kind == MF_FEAT_ONES ? nullptr : (uint32_t *)((char *)workspaces[m] + L[m].aux);
+        E.label_status = f.label_status;
+        E.abort = ticket0 + ABORT_MAPS + (m - 1);
+    }
+    MultiCtx lead = {};
+    lead.role = 0; lead.scattered = ms->scattered;
+    // what the caller's stream has produced so far (the frames, earlier updates of the maps) is visible to the side streams
+    MF_HIP_CHECK(hipEventRecord(ms->entry, st));
+    rc = run_pipeline<0>(P, &grids[0], workspaces[0], workspace_bytes[0], st, 3, &lead);
+    if (rc != MF_OK) return rc;             // nothing was issued on a side stream
+    int first_error = MF_OK, joined = 0;
+    for (int m = 1; m < n_maps; ++m) {
+        hipStream_t side = ms->side[m - 1];
+        if (hipStreamWaitEvent(side, ms->entry, 0) != hipSuccess) { first_error = fail(MF_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        FuseParams Q = {};
+        fill_grid(Q, &grids[m]);
+        fill_frames(Q, &frames[m]);
+        Q.G = G;
+        Q.iw = interpolation_weights[m];
+        MultiCtx follow = {};
+        follow.role = 1; follow.scattered = ms->scattered;
+        follow.cursor = (int *)(ws0 + L[0].cursor);
+        follow.rec = (uint4 *)(ws0 + L[0].rec);
+        follow.nonempty = ticket0 + SPLIT_NONEMPTY;
+        follow.abort = ticket0 + ABORT_MAPS + (m - 1);
+        follow.s0 = s0; follow.s1 = s1; follow.s2 = s2;
+        rc = run_pipeline<0>(Q, &grids[m], workspaces[m], workspace_bytes[m], side, 3, &follow);
+        if (rc != MF_OK && first_error == MF_OK) first_error = rc;
+        // joined whatever happened: the caller's stream continues behind everything a side stream was given
+        if (hipEventRecord(ms->done[m - 1], side) == hipSuccess && hipStreamWaitEvent(st, ms->done[m - 1], 0) == hipSuccess) ++joined;
+        else if (first_error == MF_OK) first_error = fail(MF_ERR_HIP, "joining a side stream failed");
+        if (rc != MF_OK) break;
+    }
+    (void)joined;
+    return first_error;
 }
 
 static int fuse_frames_phase(const mf_grid *grid, const mf_frames *frames, float interpolation_weight, int32_t mode,

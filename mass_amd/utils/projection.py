@@ -273,6 +273,53 @@ def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, featur
                                  wptr, wbytes, stream))
 
 
+def fuse_frame_maps(updates, sequential=True, min_ray_depth=0.0, max_ray_depth=10.0):
+    """One batch of posed frames onto several maps in one library call (mf_fuse_frame_maps): what the
+    reference's agent does with a loop of layer.update(observations) per simulator step
+    (navigation_policy.py:164-171).  `updates` is a list of dicts, one per map, with the arguments of
+    fuse_frames: bins_x, bins_y, bins_z, cam_rays, poses, depth, features, feature_map,
+    interpolation_weight, workspace, label_status.  The maps share their voxel grid (equal edges: the
+    caller's responsibility) and the frames: cam_rays, poses and depth of updates[0] are used for all.
+    The result on every map equals its own fuse_frames call; a single frame (or a merged batch) is
+    bucketed once and the maps' tile kernels run side by side."""
+    n = len(updates)
+    if n < 1 or n > _lib.MAX_MAPS_PER_CALL:
+        raise ValueError(f"1 to {_lib.MAX_MAPS_PER_CALL} maps per call, got {n}")
+    u0 = updates[0]
+    # one tensor each for rays, poses and depth: every map's argument block points at the same memory
+    cam = _f32c(u0["cam_rays"])
+    H, W = cam.shape[0], cam.shape[1]
+    depth = _f32c(u0["depth"]).reshape(-1, H, W)
+    poses = _f32c(u0["poses"]).reshape(-1, 12)
+    grids, frames = (_lib.MfGrid * n)(), (_lib.MfFrames * n)()
+    weights, wptrs, wbytes = (_lib.c_float * n)(), (_lib.c_void_p * n)(), (_lib.c_size_t * n)()
+    keep, spaces = [], []
+    for m, u in enumerate(updates):
+        g, fr, fm, B, H, W, alive = _frames_call(u["bins_x"], u["bins_y"], u["bins_z"], cam, poses, depth,
+                                                 u.get("features"), u["feature_map"], min_ray_depth, max_ray_depth,
+                                                 u.get("label_status"))
+        if sequential and B > _lib.MAX_FRAMES_PER_CALL:
+            raise ValueError(f"at most {_lib.MAX_FRAMES_PER_CALL} sequential frames per call")
+        feat = alive[2]
+        fr.n_frames = B
+        fr.poses, fr.depth = poses.data_ptr(), depth.data_ptr()
+        fr.feat = feat.data_ptr() if feat is not None else None
+        need = lib.mf_fuse_workspace_bytes(g, B * H * W, B if sequential else 1)
+        if need == 0:
+            check(_lib.MF_ERR_INVALID)
+        ws = u.get("workspace")
+        if ws is None or any(ws is w for w in spaces):
+            raise ValueError("every map of a fuse_frame_maps call needs a Workspace of its own")
+        spaces.append(ws)
+        wp, wb = ws.get(need, fm.device)
+        grids[m], frames[m] = g, fr
+        weights[m] = float(u.get("interpolation_weight", 0.5))
+        wptrs[m], wbytes[m] = wp.value, wb
+        keep.append(alive)
+    check(lib.mf_fuse_frame_maps(grids, frames, weights, n, _lib.MODE_SEQUENTIAL if sequential else _lib.MODE_MERGED,
+                                 wptrs, wbytes, current_stream(u0["feature_map"].device)))
+
+
 class FusePipeline:
     """Batch after batch into one map with the bucketing of batch k+1 overlapped with the tile
     kernels of batch k (mf_fuse_frames_stage on a side stream, mf_fuse_frames_commit in order on the

@@ -1,0 +1,194 @@
+"""update_feature_maps / mf_fuse_frame_maps: one observation onto several maps per call.
+
+The reference's agent loops `self.feature_maps[name].update(observations)` over its maps per simulator step
+(/root/reference/mass/navigation_policy.py:164-171).  The shared call buckets the frame once and runs the maps'
+tile kernels side by side: every map must end up with exactly the bits of its own layer.update() (compared
+bitwise with twin layers driven by the plain loop), which the other GPU tests tie to the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_map_close
+
+pytestmark = pytest.mark.gpu
+
+
+def make_layers(device, H, W, M, C_sem=7, C_feat=3, res=0.1, iw=0.5, extra_dense=None, origin=0.0):
+    from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+    from mass_amd.nn.applications.occupancy_projection_layer import OccupancyProjectionLayer
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    kw = dict(camera_height=H, camera_width=W, map_height=M, map_width=M, map_depth=M, grid_resolution=res,
+              interpolation_weight=iw, origin_x=origin)
+    maps = dict(occupancy=OccupancyProjectionLayer(**kw).to(device),
+                semantic=SemanticProjectionLayer(feature_size=C_sem, **kw).to(device),
+                rgb=BaseProjectionLayer(feature_size=C_feat, **kw).to(device))
+    if extra_dense:
+        maps["deep"] = BaseProjectionLayer(feature_size=extra_dense, **kw).to(device)
+    return maps
+
+
+def frames(n, H, W, C_sem, C_feat, seed, extra_dense=None):
+    from mass_amd.episodes import room_trajectory
+    tr = room_trajectory(n, H, W, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    out = dict(position=tr["position"], yaw=tr["yaw"], elevation=tr["elevation"], depth=tr["depth"],
+               semantic=(tr["semantic"].long() % C_sem).to(torch.uint8)[..., None],
+               rgb=torch.rand(n, H, W, C_feat, generator=g))
+    if extra_dense:
+        out["deep"] = torch.randn(n, H // 4, W // 4, extra_dense, generator=g)
+    return out
+
+
+def observation(fr, t, device=None, feat_key="rgb"):
+    o = dict(position=fr["position"][t], yaw=fr["yaw"][t], elevation=fr["elevation"][t], depth=fr["depth"][t],
+             semantic=fr["semantic"][t], features=fr[feat_key][t])
+    if device is not None:
+        o = {k: (v.to(device) if k in ("depth", "semantic", "features") else v) for k, v in o.items()}
+    return o
+
+
+def same(a, b, name):
+    """Bit-equal where the integer kernels ran (single frames of a real size: run-to-run identical sums); the float
+    tile kernel (small test frames, wide dense features) adds in the order its LDS atomics land, so two runs of the
+    SAME call differ in the last bits: those are held to 1e-5."""
+    if torch.equal(a, b):
+        return
+    from conftest import assert_map_close_device
+    assert_map_close_device(a, b, rtol=1e-5, atol=1e-7, what=name)
+
+
+def loop_update(maps, o, validate="defer"):
+    for name, lay in maps.items():
+        if name == "semantic":
+            lay.update(o, validate=validate)
+        else:
+            lay.update(o)
+
+
+@pytest.mark.parametrize("H,W,M,C_sem,n", [(48, 64, 32, 7, 8), (120, 160, 64, 54, 5)])
+def test_shared_call_gives_every_map_the_bits_of_its_own_update(device, H, W, M, C_sem, n):
+    from mass_amd.nn.feature_maps import update_feature_maps
+    a, b = make_layers(device, H, W, M, C_sem), make_layers(device, H, W, M, C_sem)
+    fr = frames(n, H, W, C_sem, 3, seed=4)
+    for t in range(n):
+        o = observation(fr, t, device)
+        update_feature_maps(a, o, validate="defer")
+        loop_update(b, o)
+    a["semantic"].check_labels()
+    for name in a:
+        assert int((b[name].data != 0).sum()) > 0
+        same(a[name].data, b[name].data, name)
+
+
+def test_shared_call_matches_the_oracle(device):
+    """Independent of the plain path: the three maps of the shared call against the oracle's update loop."""
+    from oracle import massref as orc
+    from mass_amd.nn.feature_maps import update_feature_maps
+    H, W, M, C_sem, n = 48, 64, 32, 6, 6
+    maps = make_layers(device, H, W, M, C_sem)
+    fr = frames(n, H, W, C_sem, 3, seed=9)
+    kw = dict(camera_height=H, camera_width=W, map_height=M, map_width=M, map_depth=M, grid_resolution=0.1,
+              interpolation_weight=0.5)
+    refs = dict(occupancy=orc.RefProjectionLayer(feature_size=1, **kw), semantic=orc.RefProjectionLayer(feature_size=C_sem, **kw),
+                rgb=orc.RefProjectionLayer(feature_size=3, **kw))
+    for t in range(n):
+        o = observation(fr, t)                                   # host tensors: uploaded once by the call
+        update_feature_maps(maps, o, update_map=["occupancy", "semantic", "rgb"])
+        base = dict(position=o["position"], yaw=o["yaw"], elevation=o["elevation"], depth=o["depth"])
+        refs["occupancy"].update(dict(base, features=torch.ones(H, W, 1)))
+        refs["semantic"].update(dict(base, features=torch.nn.functional.one_hot(o["semantic"][..., 0].long(), C_sem).float()))
+        refs["rgb"].update(dict(base, features=o["features"]))
+    for name in maps:
+        assert_map_close(maps[name].data.cpu().numpy(), refs[name].data.numpy(), what=name)
+
+
+def test_a_bad_class_id_calls_off_its_own_map_only(device):
+    from mass_amd.nn.feature_maps import update_feature_maps
+    H, W, M, C_sem = 48, 64, 32, 5
+    a, b = make_layers(device, H, W, M, C_sem), make_layers(device, H, W, M, C_sem)
+    fr = frames(3, H, W, C_sem, 3, seed=2)
+    o0 = observation(fr, 0, device)
+    update_feature_maps(a, o0)
+    loop_update(b, o0, validate=True)
+    before = a["semantic"].data.clone()
+    o1 = observation(fr, 1, device)
+    o1["semantic"] = o1["semantic"].clone()
+    o1["semantic"][7, 9] = C_sem                                  # one pixel out of range
+    with pytest.raises(RuntimeError, match="Class values"):
+        update_feature_maps(a, o1)
+    assert torch.equal(a["semantic"].data, before)                # untouched, like the reference's raise before the update
+    b["occupancy"].update(o1)
+    b["rgb"].update(o1)
+    same(a["occupancy"].data, b["occupancy"].data, "occupancy")
+    same(a["rgb"].data, b["rgb"].data, "rgb")
+    o2 = observation(fr, 2, device)                               # and the layer goes on afterwards
+    update_feature_maps(a, o2)
+    loop_update(b, o2, validate=True)
+    for name in a:
+        same(a[name].data, b[name].data, name)
+
+
+def test_four_maps_quarter_resolution_features_and_numpy_observations(device):
+    """A fourth map with 32 channels at quarter feature resolution (no single-pass path: its tiles go to
+    fuse_tiles_kernel from the shared records), observations as numpy arrays."""
+    from mass_amd.nn.feature_maps import update_feature_maps
+    H, W, M, C_sem, n = 48, 64, 32, 9, 4
+    a, b = make_layers(device, H, W, M, C_sem, extra_dense=32), make_layers(device, H, W, M, C_sem, extra_dense=32)
+    fr = frames(n, H, W, C_sem, 3, seed=6, extra_dense=32)
+    for t in range(n):
+        o = observation(fr, t)
+        host = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in o.items()}
+        host["semantic"] = host["semantic"].astype(np.int64)
+        three = {k: a[k] for k in ("occupancy", "semantic", "rgb")}
+        update_feature_maps(three, host, validate="defer")
+        # the 32-channel map takes other features: a call of its own (one map: the plain path)
+        deep_obs = dict(host, features=fr["deep"][t].numpy())
+        update_feature_maps([a["deep"]], deep_obs)
+        loop_update({k: b[k] for k in three}, observation(fr, t, device))
+        b["deep"].update(dict(observation(fr, t, device), features=fr["deep"][t].to(device)))
+    for name in a:
+        same(a[name].data, b[name].data, name)
+    # a 32-channel map in the lead of a shared call (the others take their words from its records)
+    c, d = make_layers(device, H, W, M, C_sem, extra_dense=32), make_layers(device, H, W, M, C_sem, extra_dense=32)
+    for t in range(n):
+        o = dict(observation(fr, t, device), features=fr["deep"][t].to(device))
+        update_feature_maps([c["deep"], c["occupancy"], c["semantic"]], o, validate=False)
+        d["deep"].update(o); d["occupancy"].update(o); d["semantic"].update(o, validate=False)
+    for name in ("deep", "occupancy", "semantic"):
+        same(c[name].data, d[name].data, name)
+
+
+def test_maps_of_another_grid_keep_their_own_call(device):
+    from mass_amd.nn.feature_maps import update_feature_maps, _same_geometry
+    H, W, M, C_sem = 48, 64, 32, 4
+    a, b = make_layers(device, H, W, M, C_sem), make_layers(device, H, W, M, C_sem)
+    shifted_a = make_layers(device, H, W, M, C_sem, origin=0.35)["occupancy"]
+    shifted_b = make_layers(device, H, W, M, C_sem, origin=0.35)["occupancy"]
+    assert _same_geometry(a["occupancy"], a["rgb"]) and not _same_geometry(a["occupancy"], shifted_a)
+    fr = frames(3, H, W, C_sem, 3, seed=12)
+    for t in range(3):
+        o = observation(fr, t, device)
+        update_feature_maps([a["occupancy"], shifted_a, a["semantic"], a["rgb"]], o)
+        loop_update(b, o)
+        shifted_b.update(o)
+    same(shifted_a.data, shifted_b.data, "shifted")
+    assert int((shifted_b.data != 0).sum()) > 0
+    for name in a:
+        same(a[name].data, b[name].data, name)
+    # reset() moves the edges of one map only: it leaves the group until the others follow
+    a["rgb"].reset(origin_x=0.2)
+    assert not _same_geometry(a["occupancy"], a["rgb"])
+
+
+def test_full_size_frame_three_maps(device):
+    """480 x 640 -> 256^3 (C = 1, 54, 3): the shapes config 3 of the bench runs."""
+    from mass_amd.nn.feature_maps import update_feature_maps
+    H, W, M, C_sem = 480, 640, 256, 54
+    a, b = make_layers(device, H, W, M, C_sem, res=0.05), make_layers(device, H, W, M, C_sem, res=0.05)
+    fr = frames(3, H, W, C_sem, 3, seed=1)
+    for t in range(3):
+        o = observation(fr, t, device)
+        update_feature_maps(a, o, validate="defer")
+        loop_update(b, o)
+    for name in a:
+        assert torch.equal(a[name].data, b[name].data), name      # single-pass integer kernels: identical bits
