@@ -402,41 +402,51 @@ def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
     rgb = BaseProjectionLayer(**dict(lay_kw, feature_size=3)).to(dev)
     d_dev, s_dev, c_dev = tr["depth"].to(dev), tr["semantic"].to(dev)[..., None], tr["rgb"].to(dev)
 
-    def run_traj(host_fed, validate=True):
+    from mass_amd.nn.feature_maps import update_feature_maps
+    maps = dict(occupancy=occ, semantic=sem, rgb=rgb)
+    d_np, s_np, c_np = tr["depth"].numpy(), tr["semantic"].numpy()[..., None].astype(np.int64), tr["rgb"].numpy()
+    # the observation of every step, as the simulator wrapper hands it over (built outside the timed loops)
+    obs_dev = [dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t], depth=d_dev[t],
+                    semantic=s_dev[t], features=c_dev[t]) for t in range(n3)]
+    obs_host = [dict(position=tr["position"][t].numpy(), yaw=float(tr["yaw"][t]), elevation=float(tr["elevation"][t]),
+                     depth=d_np[t], semantic=s_np[t], features=c_np[t]) for t in range(n3)]
+
+    def run_traj(host_fed, validate=True, shared=True):
         for lay in (occ, sem, rgb):
             lay.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for t in range(n3):
-            if host_fed:      # numpy observations, as the simulator hands them over (PCIe inclusive)
-                o = dict(position=tr["position"][t].numpy(), yaw=float(tr["yaw"][t]), elevation=float(tr["elevation"][t]),
-                         depth=d_np[t])
-                occ.update(o)
-                sem.update(dict(o, semantic=s_np[t]), validate=validate)
-                rgb.update(dict(o, features=c_np[t]))
+        for o in (obs_host if host_fed else obs_dev):
+            if shared:        # the agent's loop over its maps as one call (navigation_policy.py:164-171)
+                update_feature_maps(maps, o, validate=validate)
             else:
-                o = dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t], depth=d_dev[t])
                 occ.update(o)
-                sem.update(dict(o, semantic=s_dev[t]), validate=validate)
-                rgb.update(dict(o, features=c_dev[t]))
+                sem.update(o, validate=validate)
+                rgb.update(o)
         torch.cuda.synchronize()
         sem.check_labels()
         return time.perf_counter() - t0
     run_traj(False, validate="defer")
     dt = min(run_traj(False, validate="defer") for _ in range(2))
     dt_sync = min(run_traj(False, validate=True) for _ in range(2))
-    d_np, s_np, c_np = tr["depth"].numpy(), tr["semantic"].numpy()[..., None].astype(np.int64), tr["rgb"].numpy()
-    dt_host = run_traj(True, validate="defer")
+    run_traj(False, validate="defer", shared=False)
+    dt_loop = min(run_traj(False, validate="defer", shared=False) for _ in range(2))
+    dt_host = min(run_traj(True, validate="defer") for _ in range(2))
+    dt_host_loop = run_traj(True, validate="defer", shared=False)
     out["config3_trajectory_300x3maps"] = dict(
         frames_per_s=n3 / dt, ms_per_frame_3_maps=dt / n3 * 1e3, updates_per_s=3 * n3 / dt,
         frames_per_s_synchronous_label_check=n3 / dt_sync,
+        frames_per_s_layer_loop=n3 / dt_loop, ms_per_frame_layer_loop=dt_loop / n3 * 1e3,
         host_fed_frames_per_s=n3 / dt_host, host_fed_ms_per_frame=dt_host / n3 * 1e3,
-        note="per-frame layer.update() on occupancy (C=1), semantic (C=54 labels) and RGB (C=3 dense fp32) maps, "
-             "256^3 each, sequential; frames_per_s with observations resident in HBM and the default class-id check "
-             "(validate='defer': an id out of range calls the update off on the device and raises at the next call into "
-             "the layer), frames_per_s_synchronous_label_check with validate=True (update() waits for the semantic "
-             "update and raises itself, like the reference's one_hot), host_fed_* with numpy "
-             "observations uploaded per call (PCIe inclusive, int64 label image as the simulator produces it)")
+        host_fed_frames_per_s_layer_loop=n3 / dt_host_loop,
+        note="per simulator step the occupancy (C=1), semantic (C=54 labels) and RGB (C=3 dense fp32) maps, 256^3 each, "
+             "take the same observation: frames_per_s through mass_amd.nn.update_feature_maps (one mf_fuse_frame_maps "
+             "call: the frame is bucketed once, the maps' tile kernels run side by side), *_layer_loop through three "
+             "layer.update() calls like the reference's loop; observations resident in HBM, class-id check deferred "
+             "(validate='defer': an id out of range calls the map's update off on the device and raises at the next "
+             "call into the layer); frames_per_s_synchronous_label_check with validate=True (one stream wait per step, "
+             "raises from the call itself like the reference's one_hot); host_fed_* with numpy observations uploaded "
+             "per step (PCIe inclusive, int64 label image as the simulator produces it)")
     del occ, sem, rgb, d_dev, s_dev, c_dev
 
     # configs[3]: matching, 200 x 200 instance pairs, 1024-d (experimentation.py:261-287)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 4
+#define MF_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define MF_API __attribute__((visibility("default")))
@@ -97,6 +97,11 @@ typedef struct mf_frames {
                                            leaves the map untouched, like the reference, whose one_hot raises
                                            before anything is written (semantic_projection_layer.py:203-209).
                                            With NULL such ids count as an all-zero feature row.              */
+    int32_t poses_on_host;              /* 0: `poses` is device memory.  1: `poses` points at HOST memory that is
+                                           read during the call and travels as a kernel argument (n_frames must be
+                                           1): the per-step caller (one frame per update, agent.py:107-111) then
+                                           needs no upload of 48 bytes, whose copy from pageable memory makes the
+                                           host wait for the stream's earlier work                           */
 } mf_frames;
 
 MF_API int mf_version(void);

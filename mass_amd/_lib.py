@@ -20,7 +20,7 @@ FEAT_ONES, FEAT_LABEL_U8, FEAT_LABEL_I32, FEAT_LABEL_I64, FEAT_DENSE_F32 = 0, 1,
 MODE_SEQUENTIAL, MODE_MERGED = 0, 1
 METRIC_L2, METRIC_L2_GEMM, METRIC_COSINE = 0, 1, 2
 MAX_FRAMES_PER_CALL = 256
-ABI_VERSION = 4
+ABI_VERSION = 5
 MODE_TILES, MODE_DENSE, MODE_CELLS = 0, 2, 3
 MAX_MAPS_PER_CALL = 4          # mf_fuse_frame_maps          # mf_fuse_last_mode
 
@@ -49,7 +49,8 @@ class MfFrames(_SizedStruct):
     _fields_ = [("struct_size", ctypes.c_uint32), ("n_frames", c_int32), ("height", c_int32), ("width", c_int32),
                 ("cam_rays", c_void_p), ("poses", c_void_p), ("depth", c_void_p), ("feat", c_void_p),
                 ("feat_kind", c_int32), ("feat_height", c_int32), ("feat_width", c_int32),
-                ("min_depth", c_float), ("max_depth", c_float), ("label_status", c_void_p)]
+                ("min_depth", c_float), ("max_depth", c_float), ("label_status", c_void_p),
+                ("poses_on_host", c_int32)]
 
 
 # every symbol include/massfuse.h declares: name -> (restype, argtypes)

@@ -66,6 +66,8 @@ struct FuseParams {
     // frames (front end 0)
     int n_frames, H, W;
     const float *cam, *poses, *depth;
+    int pose_inline;           // the one frame's pose rides in pose0 (mf_frames.poses_on_host), `poses` is not read
+    float pose0[12];
     const void *feat;
     int feat_kind, fh, fw, rep_y, rep_x;
     float min_d, max_d;
@@ -92,6 +94,7 @@ struct FuseParams {
     uint4 *rec;
     uint32_t *aux;
     uint4 *pts;                // [n_points] (front end 0) the binned pixels, written by count_kernel for scatter_kernel
+    unsigned *absmax;          // front end 0, dense features on the single-pass path: bits of max |feature| (count_kernel), else NULL
     // further maps updated from the same frames (mf_fuse_frame_maps): they share the records, each has its own word per record
     int n_extra;
     struct ExtraMap {
@@ -100,6 +103,9 @@ struct FuseParams {
         uint32_t *aux;         // [cap] class id / feature pixel per record (NULL: ones)
         int *label_status;     // optional, as above
         int *abort;            // its tile_list_kernel lists nothing when this word is set
+        unsigned *absmax;      // as above, for this map (a word of the first map's counter block), else NULL
+        uint4 *zero;           // its counters and split scratch, zeroed here (count_kernel) ...
+        unsigned zero16;       // ... this many 16-byte words
     } extra[3];
 };
 constexpr int MAX_EXTRA_MAPS = 3;
@@ -150,7 +156,9 @@ __device__ __forceinline__ bool get_point(const FuseParams &P, long long idx, Po
         const int f = blockIdx.y;
         const int pix = (int)(idx - (long long)f * HW);
         const float d = P.depth[idx];
-        const float *pose = P.poses + f * 12;
+        float pose[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pose[k] = P.pose_inline ? P.pose0[k] : P.poses[f * 12 + k];
         float q0, q1, q2;
         rotate_ray(pose + 3, P.cam[pix * 3], P.cam[pix * 3 + 1], P.cam[pix * 3 + 2], q0, q1, q2);
         const float m0 = q0 * d, m1 = q1 * d, m2 = q2 * d;
@@ -375,6 +383,30 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
             }
         }
     }
+    if (FRONT == 0) {
+        // the counters and split scratch of the further maps (their own memset otherwise)
+        const unsigned gtid = (blockIdx.y * gridDim.x + blockIdx.x) * BIN_THREADS + threadIdx.x, gsize = gridDim.x * gridDim.y * BIN_THREADS;
+        for (int m = 0; m < P.n_extra; ++m)
+            for (unsigned i = gtid; i < P.extra[m].zero16; i += gsize) P.extra[m].zero[i] = make_uint4(0u, 0u, 0u, 0u);
+        // max |feature| of the maps whose dense features take the single-pass kernel (its fixed-point scale): every
+        // feature pixel is some pixel's (the feature image divides the frame), so the maximum over the pixels is exact
+        for (int m = -1; m < P.n_extra; ++m) {
+            unsigned *out = m < 0 ? P.absmax : P.extra[m].absmax;
+            if (!out) continue;                                    // (uniform)
+            const float *f = (const float *)(m < 0 ? P.feat : P.extra[m].feat);
+            const int Cm = m < 0 ? P.C : P.extra[m].C, fh = m < 0 ? P.fh : P.extra[m].fh, fw = m < 0 ? P.fw : P.extra[m].fw;
+            const int ry = m < 0 ? P.rep_y : P.extra[m].rep_y, rx = m < 0 ? P.rep_x : P.extra[m].rep_x;
+            unsigned mx = 0u;
+            if (idx >= 0) {
+                const int pix = (int)(idx - (long long)blockIdx.y * (P.H * P.W));
+                const int y = pix / P.W, x = pix - y * P.W;
+                const float *row = f + (((long long)blockIdx.y * fh + y / ry) * fw + x / rx) * Cm;
+                for (int c = 0; c < Cm; ++c) mx = max(mx, __float_as_uint(row[c]) & 0x7fffffffu);
+            }
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_down((int)mx, o, 64));
+            if ((threadIdx.x & 63) == 0 && mx > *(volatile unsigned *)out) atomicMax(out, mx);
+        }
+    }
     __syncthreads();
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS)
         if (hkey[s] != EMPTY) atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
@@ -542,21 +574,38 @@ constexpr int HINT_SLOT = ABORT_SLOT + 6;       // [2] records listed, non-empty
 constexpr int TICKET_DENSE = ABORT_SLOT + 8;    // work counter of fuse_dense_kernel (ticket[0] is fuse_tiles_kernel's)
 constexpr int TICKET_CELLS = ABORT_SLOT + 9;    // work counter of fuse_cells_kernel
 constexpr int ABORT_MAPS = 32;                  // [MAX_EXTRA_MAPS] abort words of the further maps of a mf_fuse_frame_maps call
+constexpr int ABSMAX_MAPS = 36;                 // [MAX_EXTRA_MAPS] their FEAT_ABSMAX words
 constexpr int MODE_TILES = 0, MODE_DENSE = 2, MODE_CELLS = 3;
 constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
 constexpr int SPLIT_PARTS_MAX = 64;
 constexpr long long SINGLE_MAX_POINTS = 1 << 21;   // calls with more points (a merged multi-frame batch) keep the tile kernel
 
-__global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ cursor /* exclusive offsets */,
-                                                        int n_tiles, int G, int *ticket, int *active,
-                                                        int split_min, int split_part, int split_slots, int *items,
-                                                        int min_mean, int first_ticket, int dense_tv,
-                                                        int first_ticket_dense, int first_ticket_cells,
-                                                        const int *abort /* a class id was out of range */,
-                                                        const int *nonempty /* buckets with entries (scan_apply_kernel) */,
-                                                        int after_scatter /* cursor[k] is the END of bucket k (scatter_kernel has run) */)
+// One list per map (blockIdx.y): the maps of a mf_fuse_frame_maps call share cursor and records, each has its counters,
+// lists, thresholds (they depend on the feature kind) and abort word.
+struct ListMap {
+    int *ticket, *active, *items;
+    int split_min, split_slots, min_mean, first_ticket, dense_tv, first_ticket_dense, first_ticket_cells;
+    const int *abort;              // a class id of this map was out of range
+};
+struct ListParams {
+    const int *cursor;             // exclusive offsets
+    int n_tiles, G, split_part;
+    const int *nonempty;           // buckets with entries (scan_apply_kernel)
+    ListMap map[1 + MAX_EXTRA_MAPS];
+};
+
+__global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
 {
+    const int *__restrict__ cursor = LP.cursor;
+    const int n_tiles = LP.n_tiles, G = LP.G, split_part = LP.split_part;
+    const int *nonempty = LP.nonempty;
+    const ListMap &M = LP.map[blockIdx.y];
+    int *ticket = M.ticket, *active = M.active, *items = M.items;
+    int split_min = M.split_min;
+    const int split_slots = M.split_slots, min_mean = M.min_mean, first_ticket = M.first_ticket, dense_tv = M.dense_tv;
+    const int first_ticket_dense = M.first_ticket_dense, first_ticket_cells = M.first_ticket_cells;
+    const int *abort = M.abort;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
         // Density of the call: records per non-empty (tile, frame) bucket and tile voxel.  Half a record per
@@ -577,7 +626,7 @@ __global__ __launch_bounds__(256) void tile_list_kernel(const int *__restrict__ 
     }
     int n = 0;
     if (*abort) return;                             // a class id was out of range: no tile is listed, the map stays as it is
-    if (t < n_tiles) n = after_scatter ? cursor[(t + 1) * G - 1] - (t > 0 ? cursor[t * G - 1] : 0) : cursor[(t + 1) * G] - cursor[t * G];
+    if (t < n_tiles) n = cursor[(t + 1) * G] - cursor[t * G];
     // A call whose tiles are sparse on average (a synthetic frame of unrelated depths: ~40 records per
     // tile) is better off in the tile kernel, which spends less per tile; a real frame (hundreds to
     // thousands of records per tile) goes to the single-pass kernel.  The whole call goes one way.
@@ -2011,6 +2060,7 @@ struct SingleParams {
     const uint4 *rec;
     const uint32_t *aux;
     const float *feat;                 // dense features (fuse_single_dense_kernel)
+    const unsigned *absmax;            // bits of their max |x| (fuse_single_dense_kernel)
     int *slot_count;                   // [slots] parts arrived
     unsigned long long *slot_ws;       // [slots][TV][2] W, S2
     unsigned long long *slot_u;        // [slots][TV * C] U (labels only; ones: U = S2)
@@ -2255,7 +2305,7 @@ __global__ __launch_bounds__(NT) void fuse_single_dense_kernel(SingleParams P)
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);
     const float fx_inv2 = fx_inv * 5.8207661e-11f;                               // 2^-34
     // |w^2 * feat| < 2^E with E from the largest |feature|: U gets fx_shift - E fraction bits
-    const unsigned mx = (unsigned)P.ticket[FEAT_ABSMAX];
+    const unsigned mx = *P.absmax;
     int E = mx ? (int)(mx >> 23) - 126 : 0;
     int shift_u = P.fx_shift - E;
     shift_u = shift_u > 56 ? 56 : (shift_u < 4 ? 4 : shift_u);
@@ -2684,6 +2734,9 @@ static int check_frames(const mf_frames *f, int C)
     if (f->n_frames < 1 || f->height < 1 || f->width < 1)
         return fail(MF_ERR_INVALID, "n_frames/height/width must be positive");
     if (!f->cam_rays || !f->poses || !f->depth) return fail(MF_ERR_INVALID, "cam_rays/poses/depth pointer is NULL");
+    if (f->poses_on_host != 0 && f->poses_on_host != 1) return fail(MF_ERR_INVALID, "poses_on_host must be 0 or 1");
+    if (f->poses_on_host && f->n_frames != 1)
+        return fail(MF_ERR_INVALID, "poses in host memory are for single-frame calls (n_frames = %d)", f->n_frames);
     if (f->feat_kind < MF_FEAT_ONES || f->feat_kind > MF_FEAT_DENSE_F32)
         return fail(MF_ERR_INVALID, "unknown feat_kind %d", f->feat_kind);
     if (f->feat_kind == MF_FEAT_ONES) {
@@ -2710,6 +2763,12 @@ static void fill_frames(FuseParams &P, const mf_frames *f)
 {
     P.n_frames = f->n_frames; P.H = f->height; P.W = f->width;
     P.cam = f->cam_rays; P.poses = f->poses; P.depth = f->depth; P.feat = f->feat;
+    P.pose_inline = 0;
+    if (f->poses_on_host) {                 // (one frame: check_frames)
+        P.pose_inline = 1;
+        for (int k = 0; k < 12; ++k) P.pose0[k] = f->poses[k];
+        P.poses = nullptr;
+    }
     P.feat_kind = f->feat_kind;
     P.fh = f->feat_kind == MF_FEAT_ONES ? f->height : f->feat_height;
     P.fw = f->feat_kind == MF_FEAT_ONES ? f->width : f->feat_width;
@@ -2734,18 +2793,33 @@ static void prof_mark(int i, hipStream_t st)
     if (g_profile && g_ev_ready && slot < PROF_CALLS) (void)hipEventRecord(g_ev[slot][i], st);
 }
 
+// The single-pass kernels (one group; class ids, ones, or dense features of few channels): LDS of a tile, and whether a call takes them
+static size_t single_lds_bytes(int feat_kind, int C, int sv)
+{
+    const bool dense = feat_kind == MF_FEAT_DENSE_F32;
+    return (feat_kind == MF_FEAT_ONES ? 0 : ((size_t)C << sv) * (dense ? 16 : 8) + ((((size_t)C << sv) + 31) / 32) * 4) + ((size_t)36 << sv) + 64;
+}
+static bool takes_single(const Layout &L, int feat_kind, int C, int sv)
+{
+    return L.split_slots > 0 && (feat_kind != MF_FEAT_DENSE_F32 || C <= SINGLE_DENSE_MAX_C) && single_lds_bytes(feat_kind, C, sv) <= 80 * 1024;
+}
+
 // Several maps updated from the same frames (mf_fuse_frame_maps): the first map's call buckets the points for all
 // of them (role 0: it also fills their per-record words and checks their class ids), a further map (role 1) takes
 // cursor and records from the first one's workspace, lists its tiles in its own and runs its tile kernels, on a
 // stream of its own, behind the first map's scatter (`scattered`).
 struct MultiCtx {
-    int role;
+    int role;                  // 0 first map, 1 further map, 2 further map, planning only: its ListMap is wanted, nothing is issued
     hipEvent_t scattered;      // recorded behind the first map's scatter_kernel
+    int n_lists;               // role 0: the further maps' list parameters (its tile_list_kernel makes all lists)
+    ListMap lists[MAX_EXTRA_MAPS];
+    ListMap *plan;             // role 2: filled in
     // role 1
     int *cursor;
     uint4 *rec;
     const int *nonempty;
     const int *abort;
+    const unsigned *absmax;
     int s0, s1, s2;            // the tile shape the records were bucketed on
 };
 
@@ -2781,7 +2855,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     P.aux = (uint32_t *)(ws + L.aux);
     P.n_tiles = P.nt0 * P.nt1 * P.nt2;
     P.n_keys = L.n_keys;
-    const bool follower = mc && mc->role == 1;
+    const bool follower = mc && mc->role >= 1;
     if (follower) {
         if (P.s0 != mc->s0 || P.s1 != mc->s1 || P.s2 != mc->s2) return fail(MF_ERR_INVALID, "maps of one call need one tile shape");
         P.cursor = mc->cursor; P.rec = mc->rec;
@@ -2789,10 +2863,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
 
     // single-pass path: one group, class ids or ones (dense features keep the tile kernel)
     const bool dense = P.feat_kind == MF_FEAT_DENSE_F32;
-    const size_t single_lds = (P.feat_kind == MF_FEAT_ONES ? 0 : ((size_t)P.C << (P.s0 + P.s1 + P.s2)) * (dense ? 16 : 8) +
-                                                                  ((((size_t)P.C << (P.s0 + P.s1 + P.s2)) + 31) / 32) * 4) +
-                              ((size_t)36 << (P.s0 + P.s1 + P.s2)) + 64;
-    const bool single = L.split_slots > 0 && (!dense || P.C <= SINGLE_DENSE_MAX_C) && single_lds <= 80 * 1024;
+    const size_t single_lds = single_lds_bytes(P.feat_kind, P.C, P.s0 + P.s1 + P.s2);
+    const bool single = takes_single(L, P.feat_kind, P.C, P.s0 + P.s1 + P.s2);
     const dim3 bin_blocks = FRONT == 0 ? dim3((unsigned)(((P.H + PATCH - 1) / PATCH) * ((P.W + PATCH - 1) / PATCH)), (unsigned)P.n_frames)
                                        : dim3((unsigned)((P.n_points + BIN_THREADS - 1) / BIN_THREADS));
     // ---- configuration of the tile kernel (needed by both halves: its grid size seeds the ticket counter) ----
@@ -2854,29 +2926,25 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     const int list_dense_tv = (use_dense || use_cells ? 1 << sv : 0) | (use_dense ? 1 << 20 : 0) | (use_cells ? 1 << 21 : 0) |
                               (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0) |
                               (P.meta ? 1 << 24 : 0);
+    ListMap LM;
+    LM.ticket = P.ticket; LM.active = P.active; LM.items = (int *)(ws + L.items);
+    LM.split_min = single ? (dense ? 0x7fffffff : split_min()) : 0; LM.split_slots = L.split_slots;
+    LM.min_mean = P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN;
+    LM.first_ticket = 4 * blocks; LM.dense_tv = list_dense_tv; LM.first_ticket_dense = 4 * blocks_dense; LM.first_ticket_cells = blocks_cells;
+    LM.abort = follower ? mc->abort : P.ticket + ABORT_SLOT;
+    if (mc && mc->role == 2) { *mc->plan = LM; return MF_OK; }
     if (follower) {
-        // own counters and split scratch, own feature range, own tile list from the shared offsets; then behind the scatter
-        MF_HIP_CHECK(hipMemsetAsync(ws + L.ticket, 0, (single ? L.active : L.slot_count) - L.ticket, st));
-        if (single && dense) {
-            const long long nf = (long long)P.n_frames * P.fh * P.fw * P.C;
-            hipLaunchKernelGGL(feat_absmax_kernel, dim3((unsigned)((nf + 256 * 16 - 1) / (256 * 16) > 1024 ? 1024 : (nf + 256 * 16 - 1) / (256 * 16))),
-                               dim3(256), 0, st, (const float *)P.feat, nf, P.ticket + FEAT_ABSMAX);
-            MF_LAUNCH_CHECK("feat_absmax_kernel");
-        }
-        // (scatter_kernel turns the bucket offsets into bucket ends as it goes: the list is made from the ends, behind it)
+        // the first map's kernels have zeroed this map's counters and split scratch, found its feature range and
+        // made its tile list: its tile kernels start behind the scatter
         MF_HIP_CHECK(hipStreamWaitEvent(st, mc->scattered, 0));
-        hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
-                           P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
-                           (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks, list_dense_tv,
-                           4 * blocks_dense, blocks_cells, mc->abort, mc->nonempty, 1);
-        MF_LAUNCH_CHECK("tile_list_kernel");
     } else if (phase & 1) {
     prof_mark(0, st);
     // cursor .. ticket (.. split scratch) are contiguous: one memset
     MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, (single ? L.active : L.slot_count) - L.cursor, st));
+    P.absmax = FRONT == 0 && single && dense ? (unsigned *)(P.ticket + FEAT_ABSMAX) : nullptr;     // found by count_kernel itself
     hipLaunchKernelGGL(count_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
-    if (single && dense) {
+    if (FRONT != 0 && single && dense) {
         const long long nf = FRONT == 0 ? (long long)P.n_frames * P.fh * P.fw * P.C : P.n_points * P.C;
         hipLaunchKernelGGL(feat_absmax_kernel, dim3((unsigned)((nf + 256 * 16 - 1) / (256 * 16) > 1024 ? 1024 : (nf + 256 * 16 - 1) / (256 * 16))),
                            dim3(256), 0, st, (const float *)P.feat, nf, P.ticket + FEAT_ABSMAX);
@@ -2889,11 +2957,16 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     hipLaunchKernelGGL(scan_apply_kernel, dim3(L.n_scan_blocks), dim3(SCAN_THREADS), 0, st,
                        P.cursor, P.n_keys + 1, (const int *)P.block_sums, P.ticket + SPLIT_NONEMPTY);
     MF_LAUNCH_CHECK("scan_apply_kernel");
-    hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256), dim3(256), 0, st, (const int *)P.cursor,
-                       P.n_tiles, P.G, P.ticket, P.active, single ? (dense ? 0x7fffffff : split_min()) : 0, split_part(), L.split_slots,
-                       (int *)(ws + L.items), P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN, 4 * blocks, list_dense_tv,
-                       4 * blocks_dense, blocks_cells, (const int *)(P.ticket + ABORT_SLOT), (const int *)(P.ticket + SPLIT_NONEMPTY), 0);
-    MF_LAUNCH_CHECK("tile_list_kernel");
+    {
+        ListParams LP;
+        LP.cursor = P.cursor; LP.n_tiles = P.n_tiles; LP.G = P.G; LP.split_part = split_part();
+        LP.nonempty = P.ticket + SPLIT_NONEMPTY;
+        LP.map[0] = LM;
+        const int n_lists = mc && mc->role == 0 ? mc->n_lists : 0;
+        for (int m = 0; m < n_lists; ++m) LP.map[1 + m] = mc->lists[m];
+        hipLaunchKernelGGL(tile_list_kernel, dim3((P.n_tiles + 255) / 256, 1 + n_lists), dim3(256), 0, st, LP);
+        MF_LAUNCH_CHECK("tile_list_kernel");
+    }
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
@@ -3002,6 +3075,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         S.s0 = P.s0; S.s1 = P.s1; S.s2 = P.s2; S.nt1 = P.nt1; S.nt2 = P.nt2; S.magicC = P.magicC; S.fx_shift = T.fx_shift;
         S.cursor = P.cursor; S.ticket = P.ticket; S.items = (const int *)(ws + L.items); S.rec = P.rec; S.aux = P.aux;
         S.feat = (const float *)P.feat;
+        S.absmax = follower ? mc->absmax : (const unsigned *)(P.ticket + FEAT_ABSMAX);
         S.slot_count = (int *)(ws + L.slot_count); S.slot_ws = (unsigned long long *)(ws + L.slot_ws);
         S.slot_u = (unsigned long long *)(ws + L.slot_u);
         S.slot_bits = (unsigned *)(ws + L.slot_bits);
@@ -3141,7 +3215,7 @@ int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpola
 struct MapStreams {
     int device = -1;
     hipStream_t side[MAX_EXTRA_MAPS] = {};
-    hipEvent_t entry = nullptr, scattered = nullptr, done[MAX_EXTRA_MAPS] = {};
+    hipEvent_t scattered = nullptr, done[MAX_EXTRA_MAPS] = {};
 };
 
 static int map_streams(MapStreams *&out)
@@ -3157,7 +3231,6 @@ static int map_streams(MapStreams *&out)
         MF_HIP_CHECK(hipStreamCreateWithFlags(&m.side[i], hipStreamNonBlocking));
         MF_HIP_CHECK(hipEventCreateWithFlags(&m.done[i], hipEventDisableTiming));
     }
-    MF_HIP_CHECK(hipEventCreateWithFlags(&m.entry, hipEventDisableTiming));
     MF_HIP_CHECK(hipEventCreateWithFlags(&m.scattered, hipEventDisableTiming));
     pool.push_back(m);
     out = &pool.back();
@@ -3181,7 +3254,8 @@ int mf_fuse_frame_maps(const mf_grid *grids, const mf_frames *frames, const floa
             return fail(MF_ERR_INVALID, "map %d is %d x %d x %d, map 0 is %d x %d x %d: the maps of one call share their voxel grid",
                         m, g.size0, g.size1, g.size2, g0.size0, g0.size1, g0.size2);
         if (f.n_frames != f0.n_frames || f.height != f0.height || f.width != f0.width || f.cam_rays != f0.cam_rays ||
-            f.poses != f0.poses || f.depth != f0.depth || f.min_depth != f0.min_depth || f.max_depth != f0.max_depth)
+            f.poses != f0.poses || f.poses_on_host != f0.poses_on_host || f.depth != f0.depth || f.min_depth != f0.min_depth ||
+            f.max_depth != f0.max_depth)
             return fail(MF_ERR_INVALID, "frames[%d] differs from frames[0] in more than its features: the maps of one call "
                         "are updated from the same rays, poses and depth", m);
         for (int k = 0; k < m; ++k)
@@ -3234,17 +3308,36 @@ int mf_fuse_frame_maps(const mf_grid *grids, const mf_frames *frames, const floa
         E.aux = f.feat_kind == MF_FEAT_ONES ? nullptr : (uint32_t *)((char *)workspaces[m] + L[m].aux);
         E.label_status = f.label_status;
         E.abort = ticket0 + ABORT_MAPS + (m - 1);
+        const int sv = s0 + s1 + s2;
+        const bool single_m = takes_single(L[m], f.feat_kind, E.C, sv);
+        E.absmax = single_m && f.feat_kind == MF_FEAT_DENSE_F32 ? (unsigned *)(ticket0 + ABSMAX_MAPS + (m - 1)) : nullptr;
+        E.zero = (uint4 *)((char *)workspaces[m] + L[m].ticket);
+        E.zero16 = (unsigned)(((single_m ? L[m].active : L[m].slot_count) - L[m].ticket) / 16);
     }
     MultiCtx lead = {};
     lead.role = 0; lead.scattered = ms->scattered;
-    // what the caller's stream has produced so far (the frames, earlier updates of the maps) is visible to the side streams
-    MF_HIP_CHECK(hipEventRecord(ms->entry, st));
+    // the further maps' list parameters come from their own configuration (workspace layout, tile kernel grids)
+    lead.n_lists = n_maps - 1;
+    for (int m = 1; m < n_maps; ++m) {
+        FuseParams Q = {};
+        fill_grid(Q, &grids[m]);
+        fill_frames(Q, &frames[m]);
+        Q.G = G;
+        Q.iw = interpolation_weights[m];
+        MultiCtx plan = {};
+        plan.role = 2; plan.abort = ticket0 + ABORT_MAPS + (m - 1);
+        plan.s0 = s0; plan.s1 = s1; plan.s2 = s2;
+        plan.plan = &lead.lists[m - 1];
+        rc = run_pipeline<0>(Q, &grids[m], workspaces[m], workspace_bytes[m], st, 3, &plan);
+        if (rc != MF_OK) return rc;
+    }
+    // (a side stream starts behind the first map's scatter_kernel: what the caller's stream holds at the call - the
+    // frames, earlier updates of the maps - is ordered before it)
     rc = run_pipeline<0>(P, &grids[0], workspaces[0], workspace_bytes[0], st, 3, &lead);
     if (rc != MF_OK) return rc;             // nothing was issued on a side stream
     int first_error = MF_OK, joined = 0;
     for (int m = 1; m < n_maps; ++m) {
         hipStream_t side = ms->side[m - 1];
-        if (hipStreamWaitEvent(side, ms->entry, 0) != hipSuccess) { first_error = fail(MF_ERR_HIP, "hipStreamWaitEvent failed"); break; }
         FuseParams Q = {};
         fill_grid(Q, &grids[m]);
         fill_frames(Q, &frames[m]);
@@ -3256,6 +3349,7 @@ int mf_fuse_frame_maps(const mf_grid *grids, const mf_frames *frames, const floa
         follow.rec = (uint4 *)(ws0 + L[0].rec);
         follow.nonempty = ticket0 + SPLIT_NONEMPTY;
         follow.abort = ticket0 + ABORT_MAPS + (m - 1);
+        follow.absmax = (const unsigned *)(ticket0 + ABSMAX_MAPS + (m - 1));
         follow.s0 = s0; follow.s1 = s1; follow.s2 = s2;
         rc = run_pipeline<0>(Q, &grids[m], workspaces[m], workspace_bytes[m], side, 3, &follow);
         if (rc != MF_OK && first_error == MF_OK) first_error = rc;
@@ -3352,7 +3446,7 @@ int mf_unproject_bin(const mf_grid *grid, const mf_frames *frames, int64_t *ind_
     int rc = check_grid(grid, true);
     if (rc != MF_OK) return rc;
     if (!frames || frames->struct_size != sizeof(mf_frames) || !frames->cam_rays || !frames->poses || !frames->depth ||
-        frames->n_frames < 1)
+        frames->n_frames < 1 || (frames->poses_on_host && frames->n_frames != 1))
         return fail(MF_ERR_INVALID, "frames incomplete (or mf_frames.struct_size != %zu)", sizeof(mf_frames));
     FuseParams P = {};
     fill_grid(P, grid);

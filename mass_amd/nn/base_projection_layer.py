@@ -85,7 +85,8 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         """Host-side pose math with the reference's torch ops on the CPU
         (projection.py:29-31,104-105; base_projection_layer.py:330-331), so the
         device never evaluates sin/cos and the rotation is bit-identical to the
-        reference CPU path.  Returns device [B, 12].
+        reference CPU path.  Returns [B, 12]: on the device for a batch, on the host for one frame
+        (its 12 floats travel with the call, mf_frames.poses_on_host).
 
         agent.py updates several maps with the same observation per simulator step
         (navigation_policy.py:167-171): the packed pose of the last single-frame call is
@@ -99,9 +100,12 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
             hit = _POSE_CACHE.get("key") == key
             if hit:
                 return _POSE_CACHE["pose"]
-        eye = spherical_to_cartesian(yaw, elevation)
-        up = spherical_to_cartesian(yaw, elevation + np.pi / 2)
-        pose = pack_poses(position, eye, up).to(self.data.device, non_blocking=True)
+        # eye and up vector in one evaluation of the reference's expression (elementwise: the same bits as two)
+        n = yaw.shape[0]
+        both = spherical_to_cartesian(torch.cat([yaw, yaw]), torch.cat([elevation, elevation + np.pi / 2]))
+        pose = pack_poses(position, both[:n], both[n:])
+        if pose.shape[0] != 1:          # one frame: the 12 floats travel with the call (mf_frames.poses_on_host); an upload from
+            pose = pose.to(self.data.device, non_blocking=True)      # pageable memory would wait for the stream's earlier work
         if key is not None:
             _POSE_CACHE["key"], _POSE_CACHE["pose"] = key, pose
         return pose

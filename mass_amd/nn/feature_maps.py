@@ -35,23 +35,29 @@ def _select(feature_maps, update_map) -> List[Any]:
     return list(feature_maps)
 
 
+_PLAIN_UPDATES = (BaseProjectionLayer.update, OccupancyProjectionLayer.update, SemanticProjectionLayer.update)
+
+
 def _plain_update(lay) -> bool:
     """The layer's update() is one of the three this module knows how to restate (a subclass that
     overrides update(), like ResNetProjectionLayer with its subsampled depth, keeps its own call)."""
-    return type(lay).update in (BaseProjectionLayer.update, OccupancyProjectionLayer.update, SemanticProjectionLayer.update)
+    return type(lay).update in _PLAIN_UPDATES
 
 
-def _geometry_tensors(lay):
-    return (lay.rays, lay.bins_x, lay.bins_y, lay.bins_z)
+def _geometry_stamp(lay):
+    """Identity and version of the tensors that fix where a pixel lands: camera rays and voxel edges."""
+    b = lay._buffers
+    r, x, y, z = b["rays"], b["bins_x"], b["bins_y"], b["bins_z"]
+    return (r.data_ptr(), r._version, x.data_ptr(), x._version, y.data_ptr(), y._version, z.data_ptr(), z._version)
 
 
 def _same_geometry(a, b) -> bool:
     """Equal voxel edges and camera rays, by value (looked at once per version of the tensors: reset()
     rewrites the edges)."""
-    ta, tb = _geometry_tensors(a), _geometry_tensors(b)
-    key = tuple((t.data_ptr(), t._version) for t in ta + tb)
+    key = (_geometry_stamp(a), _geometry_stamp(b))
     hit = _SAME_GEOMETRY.get(key)
     if hit is None:
+        ta, tb = [(l.rays, l.bins_x, l.bins_y, l.bins_z) for l in (a, b)]
         hit = (a.data.shape[:3] == b.data.shape[:3] and a.data.device == b.data.device and
                all(x.shape == y.shape and x.dtype == y.dtype and bool(torch.equal(x, y)) for x, y in zip(ta, tb)))
         if len(_SAME_GEOMETRY) > 256:
@@ -79,12 +85,6 @@ def update_feature_maps(feature_maps: Union[Mapping[str, Any], Sequence[Any]],
         return
     sem_validate = "defer" if validate is True else validate
 
-    def run(lay):
-        if isinstance(lay, SemanticProjectionLayer):
-            lay.update(observations, validate=sem_validate)
-        else:
-            lay.update(observations)
-
     group: List[Any] = []
     if shared:
         for lay in layers:
@@ -93,37 +93,49 @@ def update_feature_maps(feature_maps: Union[Mapping[str, Any], Sequence[Any]],
                 group.append(lay)
     if len(group) < 2:
         group = []
-    rest = [lay for lay in layers if all(lay is not g for g in group)]
 
     if group:
-        dev = group[0].data.device
-        observations = dict(observations)
-        for key in ("depth", "features", "semantic"):       # host arrays: one upload for all maps
-            value = observations.get(key)
-            if value is not None and not (isinstance(value, torch.Tensor) and value.device == dev):
+        lead = group[0]
+        dev = lead.data.device
+        uploaded = {}
+
+        def on_device(key):           # host arrays: one upload for all maps
+            value = observations[key]
+            if isinstance(value, torch.Tensor) and value.device == dev:
+                return value
+            if key not in uploaded:
                 if isinstance(value, np.ndarray) and not value.flags.writeable:
                     value = value.copy()
-                observations[key] = torch.as_tensor(value).to(dev, non_blocking=True)
-        depth = torch.as_tensor(observations["depth"], dtype=torch.float32, device=dev)
-        poses = group[0]._poses(observations["position"], observations["yaw"], observations["elevation"])
+                uploaded[key] = torch.as_tensor(value).to(dev, non_blocking=True)
+            return uploaded[key]
+
+        depth = on_device("depth")
+        poses = lead._poses(observations["position"], observations["yaw"], observations["elevation"])
         updates = []
         for lay in group:
             features, status = None, None
             if isinstance(lay, SemanticProjectionLayer):
                 if sem_validate:
                     lay.check_labels(synchronize=False)
-                features = lay._labels(observations["semantic"])
+                features = lay._labels(on_device("semantic"))
                 status = lay._status() if sem_validate else None
             elif not isinstance(lay, OccupancyProjectionLayer):
-                features = torch.as_tensor(observations["features"], dtype=lay.data.dtype, device=dev)
+                features = on_device("features")
+                if features.dtype != lay.data.dtype:
+                    features = features.to(lay.data.dtype)
             lay._map_version += 1
-            updates.append(dict(bins_x=lay.bins_x, bins_y=lay.bins_y, bins_z=lay.bins_z, cam_rays=group[0].rays,
-                                poses=poses, depth=depth, features=features, feature_map=lay.data,
-                                interpolation_weight=lay.interpolation_weight, workspace=lay._workspace,
-                                label_status=status))
+            b = lay._buffers
+            updates.append(dict(bins_x=b["bins_x"], bins_y=b["bins_y"], bins_z=b["bins_z"], features=features,
+                                feature_map=lay.data, interpolation_weight=lay.interpolation_weight,
+                                workspace=lay._workspace, label_status=status))
+        updates[0].update(cam_rays=lead._buffers["rays"], poses=poses, depth=depth)
         fuse_frame_maps(updates, sequential=True)
-    for lay in rest:
-        run(lay)
+    for lay in layers:
+        if not any(lay is g for g in group):
+            if isinstance(lay, SemanticProjectionLayer):
+                lay.update(observations, validate=sem_validate)
+            else:
+                lay.update(observations)
     if validate is True:
         sem = [lay for lay in layers if isinstance(lay, SemanticProjectionLayer)]
         if sem:

@@ -13,6 +13,8 @@ a HIP device (no CPU fallback).  ``fuse_frames`` is the fused entry the layers
 use (transform + bin + update in one pipeline, nothing materialised).
 """
 import numpy as np
+import ctypes
+
 import torch
 
 from mass_amd import _lib
@@ -211,13 +213,15 @@ def _frames_call(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, featu
     """Argument blocks of the C ABI for a batch of posed frames: (grid struct, frames struct, B, H, W,
     tensors that must stay alive until the call is issued)."""
     fm = _check_map(feature_map)
-    require_device(bins_x, bins_y, bins_z, cam_rays, poses, depth, features)
+    require_device(bins_x, bins_y, bins_z, cam_rays, depth, features)
     H, W = cam_rays.shape[0], cam_rays.shape[1]
     depth = _f32c(depth).reshape(-1, H, W)
     B = depth.shape[0]
     poses = _f32c(poses).reshape(-1, 12)
     if poses.shape[0] != B:
         raise ValueError("one pose row per frame expected")
+    if not poses.is_cuda and B != 1:            # a single frame's pose may stay on the host (mf_frames.poses_on_host)
+        require_device(poses)
     C = fm.shape[-1]
     kind, feat = _feature_kind(features, C)
     fr = _lib.MfFrames()
@@ -227,6 +231,7 @@ def _frames_call(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, featu
     fr.min_depth, fr.max_depth = float(min_ray_depth), float(max_ray_depth)
     fr.feat_kind = kind
     fr.label_status = label_status.data_ptr() if label_status is not None else None
+    fr.poses_on_host = 0 if poses.is_cuda else 1
     if kind == _lib.FEAT_DENSE_F32:
         feat = feat.reshape(B, -1, feat.shape[-2], C) if feat.dim() >= 3 else feat
         fr.feat_height, fr.feat_width = feat.shape[1], feat.shape[2]
@@ -291,33 +296,71 @@ def fuse_frame_maps(updates, sequential=True, min_ray_depth=0.0, max_ray_depth=1
     H, W = cam.shape[0], cam.shape[1]
     depth = _f32c(u0["depth"]).reshape(-1, H, W)
     poses = _f32c(u0["poses"]).reshape(-1, 12)
+    B = depth.shape[0]
+    if poses.shape[0] != B:
+        raise ValueError("one pose row per frame expected")
+    if sequential and B > _lib.MAX_FRAMES_PER_CALL:
+        raise ValueError(f"at most {_lib.MAX_FRAMES_PER_CALL} sequential frames per call")
+    require_device(cam, depth)
+    if not poses.is_cuda and B != 1:            # a single frame's pose may stay on the host (mf_frames.poses_on_host)
+        require_device(poses)
     grids, frames = (_lib.MfGrid * n)(), (_lib.MfFrames * n)()
     weights, wptrs, wbytes = (_lib.c_float * n)(), (_lib.c_void_p * n)(), (_lib.c_size_t * n)()
     keep, spaces = [], []
     for m, u in enumerate(updates):
-        g, fr, fm, B, H, W, alive = _frames_call(u["bins_x"], u["bins_y"], u["bins_z"], cam, poses, depth,
-                                                 u.get("features"), u["feature_map"], min_ray_depth, max_ray_depth,
-                                                 u.get("label_status"))
-        if sequential and B > _lib.MAX_FRAMES_PER_CALL:
-            raise ValueError(f"at most {_lib.MAX_FRAMES_PER_CALL} sequential frames per call")
-        feat = alive[2]
-        fr.n_frames = B
-        fr.poses, fr.depth = poses.data_ptr(), depth.data_ptr()
-        fr.feat = feat.data_ptr() if feat is not None else None
-        need = lib.mf_fuse_workspace_bytes(g, B * H * W, B if sequential else 1)
-        if need == 0:
-            check(_lib.MF_ERR_INVALID)
+        fm = _check_map(u["feature_map"])
+        C = fm.shape[-1]
+        kind, feat = _feature_kind(u.get("features"), C)
+        fr = frames[m]
+        fr.struct_size = ctypes.sizeof(_lib.MfFrames)
+        fr.n_frames, fr.height, fr.width = B, H, W
+        fr.cam_rays, fr.poses, fr.depth = cam.data_ptr(), poses.data_ptr(), depth.data_ptr()
+        fr.min_depth, fr.max_depth = float(min_ray_depth), float(max_ray_depth)
+        fr.poses_on_host = 0 if poses.is_cuda else 1
+        fr.feat_kind = kind
+        status = u.get("label_status")
+        fr.label_status = status.data_ptr() if status is not None else None
+        if feat is not None:
+            require_device(feat)
+            if kind == _lib.FEAT_DENSE_F32:
+                feat = feat.reshape(B, -1, feat.shape[-2], C) if feat.dim() >= 3 else feat
+            else:
+                feat = feat.reshape(B, feat.shape[-2], feat.shape[-1])
+            fr.feat_height, fr.feat_width = feat.shape[1], feat.shape[2]
+            fr.feat = feat.data_ptr()
+        bx, by, bz = u["bins_x"], u["bins_y"], u["bins_z"]
+        if not (bx.dtype == by.dtype == bz.dtype == torch.float32 and bx.is_contiguous() and by.is_contiguous() and bz.is_contiguous()):
+            bx, by, bz = _f32c(bx), _f32c(by), _f32c(bz)
+        require_device(bx, by, bz)
+        g = grids[m]
+        g.struct_size = ctypes.sizeof(_lib.MfGrid)
+        g.size0, g.size1, g.size2, g.channels = fm.shape
+        g.bins_x, g.bins_y, g.bins_z = bx.data_ptr(), by.data_ptr(), bz.data_ptr()
+        g.n_edges_x, g.n_edges_y, g.n_edges_z = bx.numel(), by.numel(), bz.numel()
+        g.map = fm.data_ptr()
+        G = B if sequential else 1
+        wkey = (g.size0, g.size1, g.size2, g.channels, B * H * W, G)
+        need = _WORKSPACE_BYTES.get(wkey)
+        if need is None:
+            need = lib.mf_fuse_workspace_bytes(g, B * H * W, G)
+            if need == 0:
+                check(_lib.MF_ERR_INVALID)
+            if len(_WORKSPACE_BYTES) > 256:
+                _WORKSPACE_BYTES.clear()
+            _WORKSPACE_BYTES[wkey] = need
         ws = u.get("workspace")
         if ws is None or any(ws is w for w in spaces):
             raise ValueError("every map of a fuse_frame_maps call needs a Workspace of its own")
         spaces.append(ws)
         wp, wb = ws.get(need, fm.device)
-        grids[m], frames[m] = g, fr
         weights[m] = float(u.get("interpolation_weight", 0.5))
         wptrs[m], wbytes[m] = wp.value, wb
-        keep.append(alive)
+        keep.append((feat, bx, by, bz))
     check(lib.mf_fuse_frame_maps(grids, frames, weights, n, _lib.MODE_SEQUENTIAL if sequential else _lib.MODE_MERGED,
                                  wptrs, wbytes, current_stream(u0["feature_map"].device)))
+
+
+_WORKSPACE_BYTES = {}      # (map shape, points, groups) -> mf_fuse_workspace_bytes (a pure function of them)
 
 
 class FusePipeline:
@@ -386,11 +429,13 @@ class FusePipeline:
 def unproject_bin(bins_x, bins_y, bins_z, cam_rays, poses, depth, min_ray_depth=0.0, max_ray_depth=10.0):
     """Fused transform_rays + bin_rays (uncompacted), in the (x, y, z) order of
     bin_rays as BaseProjectionLayer.update calls it; parity/debug entry."""
-    require_device(bins_x, bins_y, bins_z, cam_rays, poses, depth)
+    require_device(bins_x, bins_y, bins_z, cam_rays, depth)
     H, W = cam_rays.shape[0], cam_rays.shape[1]
     depth = _f32c(depth).reshape(-1, H, W)
     B = depth.shape[0]
     poses = _f32c(poses).reshape(B, 12)
+    if not poses.is_cuda and B != 1:            # a single frame's pose may stay on the host (mf_frames.poses_on_host)
+        require_device(poses)
     cam = _f32c(cam_rays)
     bx, by, bz = _f32c(bins_x), _f32c(bins_y), _f32c(bins_z)
     dummy = torch.empty(1, dtype=torch.float32, device=depth.device)
@@ -402,6 +447,7 @@ def unproject_bin(bins_x, bins_y, bins_z, cam_rays, poses, depth, min_ray_depth=
     fr = _lib.MfFrames()
     fr.n_frames, fr.height, fr.width = B, H, W
     fr.cam_rays, fr.poses, fr.depth = cam.data_ptr(), poses.data_ptr(), depth.data_ptr()
+    fr.poses_on_host = 0 if poses.is_cuda else 1
     fr.min_depth, fr.max_depth = float(min_ray_depth), float(max_ray_depth)
     dev = depth.device
     ind = [torch.empty((B, H, W), dtype=torch.int64, device=dev) for _ in range(3)]

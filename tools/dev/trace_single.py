@@ -17,6 +17,13 @@ sem = SemanticProjectionLayer(feature_size=54, **kw).to(dev)
 rgb = BaseProjectionLayer(feature_size=3, **kw).to(dev)
 d, s, c = tr["depth"].to(dev), tr["semantic"].to(dev)[..., None], tr["rgb"].to(dev)
 from mass_amd.nn.feature_maps import update_feature_maps
+from mass_amd.utils import projection as _pj
+_real = _pj.lib.mf_fuse_frame_maps
+_acc = [0.0, 0]
+def _timed(*a):
+    t = time.perf_counter(); r = _real(*a); _acc[0] += time.perf_counter() - t; _acc[1] += 1; return r
+if os.environ.get("TIME_C"):
+    _pj.lib.mf_fuse_frame_maps = _timed
 maps = dict(occupancy=occ, semantic=sem, rgb=rgb)
 mode = sys.argv[2] if len(sys.argv) > 2 else "loop"
 for rep in range(3):
@@ -32,7 +39,9 @@ for rep in range(3):
             update_feature_maps(maps, dict(o, semantic=s[t], features=c[t]), validate="defer", shared=mode == "shared")
     t1 = time.perf_counter()
     torch.cuda.synchronize()
-    print("ms per frame (3 maps)", (time.perf_counter() - t0) / n * 1e3, "issue only", (t1 - t0) / n * 1e3, flush=True)
+    print("ms per frame (3 maps)", (time.perf_counter() - t0) / n * 1e3, "issue only", (t1 - t0) / n * 1e3,
+          "C call us", _acc[0] / max(_acc[1], 1) * 1e6, flush=True)
+    _acc[0] = 0.0; _acc[1] = 0
 
 if mode != 'loop':
     sys.exit(0)
