@@ -169,7 +169,8 @@ MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float in
  * (its own map buffer, channels, features, label_status, blend weight, workspace); the maps share
  * their voxel grid (sizes; the edges of grids[0] are the ones used - the caller passes maps whose
  * edges are equal) and the frames their rays, poses and depth.  n_maps <= 4.
- * The result on every map is that of its own mf_fuse_frames call, bit for bit.  A single group
+ * The result on every map is that of its own mf_fuse_frames call (the same bits wherever that call
+ * takes the all-integer single-pass kernels, i.e. frames of a real scene).  A single group
  * (one frame, or MF_MODE_MERGED) is bucketed ONCE - the points, their tiles and records do not
  * depend on the features - and the maps' tile kernels run side by side on streams the library
  * keeps per host thread, forked after what `stream` holds at the call and joined into it before

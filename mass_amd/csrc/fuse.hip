@@ -2929,7 +2929,10 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     ListMap LM;
     LM.ticket = P.ticket; LM.active = P.active; LM.items = (int *)(ws + L.items);
     LM.split_min = single ? (dense ? 0x7fffffff : split_min()) : 0; LM.split_slots = L.split_slots;
-    LM.min_mean = P.feat_kind == MF_FEAT_ONES ? 0 : SINGLE_MIN_MEAN;
+    static const int single_min_mean = env_int("MF_SINGLE_MIN_MEAN", 0, 1 << 20, SINGLE_MIN_MEAN);      // dev
+    // (the maps of a shared call always take the single-pass kernels when they can: a tile kernel launched only to find
+    // that it has nothing to do waits for a whole CU's LDS beside the other maps' kernels, 40 us in their way)
+    LM.min_mean = P.feat_kind == MF_FEAT_ONES || mc ? 0 : single_min_mean;
     LM.first_ticket = 4 * blocks; LM.dense_tv = list_dense_tv; LM.first_ticket_dense = 4 * blocks_dense; LM.first_ticket_cells = blocks_cells;
     LM.abort = follower ? mc->abort : P.ticket + ABORT_SLOT;
     if (mc && mc->role == 2) { *mc->plan = LM; return MF_OK; }
@@ -3014,7 +3017,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     T.meta = P.meta;
     // with ones features every tile of a single-group call goes to the single-pass kernel (tile_list_kernel,
     // min_mean = 0): nothing is listed for the tile kernel, whose launch is skipped
-    if (!(single && P.feat_kind == MF_FEAT_ONES)) {
+    if (!(single && LM.min_mean == 0)) {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, st, T);  // returns at once when the call went to another kernel
         MF_LAUNCH_CHECK("fuse_tiles_kernel");
     }
@@ -3263,6 +3266,27 @@ int mf_fuse_frame_maps(const mf_grid *grids, const mf_frames *frames, const floa
     }
     hipStream_t st = (hipStream_t)stream;
     const int G = mode == MF_MODE_SEQUENTIAL ? frames[0].n_frames : 1;
+    // The map whose tile kernels take longest leads (they start right behind the scatter on the caller's stream; the
+    // others cross to a side stream and back): dense features before class ids before ones, more channels first.
+    mf_grid grids_o[1 + MAX_EXTRA_MAPS];
+    mf_frames frames_o[1 + MAX_EXTRA_MAPS];
+    float weights_o[1 + MAX_EXTRA_MAPS];
+    void *workspaces_o[1 + MAX_EXTRA_MAPS];
+    size_t workspace_bytes_o[1 + MAX_EXTRA_MAPS];
+    {
+        int order[1 + MAX_EXTRA_MAPS];
+        auto load = [&](int m) {
+            return (frames[m].feat_kind == MF_FEAT_DENSE_F32 ? 1 << 20 : frames[m].feat_kind == MF_FEAT_ONES ? 0 : 1 << 16) + grids[m].channels;
+        };
+        for (int m = 0; m < n_maps; ++m) order[m] = m;
+        for (int i = 1; i < n_maps; ++i)              // (stable insertion sort, n_maps <= 4)
+            for (int j = i; j > 0 && load(order[j]) > load(order[j - 1]); --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+        for (int m = 0; m < n_maps; ++m) {
+            grids_o[m] = grids[order[m]]; frames_o[m] = frames[order[m]]; weights_o[m] = interpolation_weights[order[m]];
+            workspaces_o[m] = workspaces[order[m]]; workspace_bytes_o[m] = workspace_bytes[order[m]];
+        }
+        grids = grids_o; frames = frames_o; interpolation_weights = weights_o; workspaces = workspaces_o; workspace_bytes = workspace_bytes_o;
+    }
     // what is shared is the bucketing of a single group; anything else (and maps whose tiles differ) is the plain loop
     bool share = n_maps > 1 && G == 1;
     int s0 = 0, s1 = 0, s2 = 0;
