@@ -184,7 +184,8 @@ def test_bench_two_ranks_share_the_gpu_and_allreduce(device):
     (torch.distributed.run) before touching the GPU; with MF_BENCH_BACKEND=gloo both ranks use
     this box's one GPU.  Every rank fuses the same frames here, so the all-reduced counters must
     be exactly twice the single-process ones."""
-    one = run_bench(["--gpus", "1"])
+    # (--rank-seed-stride 0: every rank, and every one of a rank's rotating batches, is the batch of seed 0)
+    one = run_bench(["--gpus", "1", "--rank-seed-stride", "0"])
     two = run_bench(["--gpus", "2", "--rank-seed-stride", "0"], {"MF_BENCH_BACKEND": "gloo"})
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     for k in ("frames", "valid_points", "touched_voxels", "union_voxels"):
