@@ -207,24 +207,31 @@ __device__ __forceinline__ long long point_index(const FuseParams &P, int thread
     return idx < P.n_points ? idx : -1;
 }
 
-// The <=8 (tile, group) buckets a point's footprint overlaps.
-__device__ __forceinline__ int point_keys(const FuseParams &P, const Point &pt, uint32_t keys[8])
+// The <= 8 (tile, group) buckets a point's footprint overlaps, at fixed positions: key[4 a + 2 b + c] for the lower / upper tile per axis, bit j of the result set
+// where the combination is a tile of its own (an axis whose two corners share a tile counts once, as a = 0).  Fixed
+// positions keep keys, slots and ranks of count_kernel / scatter_kernel in registers (unrolled loops, no indexed arrays)
+// and let scatter_kernel have the returning atomics of all of a point's buckets in flight before the first record store.
+struct TileKeys {
+    uint32_t key[8];
+    unsigned mask;
+    AxisFoot a0, a1, a2;
+    int t0[2], t1[2], t2[2];
+};
+__device__ __forceinline__ void point_keys8(const FuseParams &P, const Point &pt, TileKeys &K)
 {
-    const AxisFoot a0 = axis_foot(pt.k0, pt.r0, P.size0);
-    const AxisFoot a1 = axis_foot(pt.k1, pt.r1, P.size1);
-    const AxisFoot a2 = axis_foot(pt.k2, pt.r2, P.size2);
-    const int t0[2] = {a0.lo >> P.s0, a0.hi >> P.s0};
-    const int t1[2] = {a1.lo >> P.s1, a1.hi >> P.s1};
-    const int t2[2] = {a2.lo >> P.s2, a2.hi >> P.s2};
-    const int m0 = t0[0] != t0[1] ? 2 : 1, m1 = t1[0] != t1[1] ? 2 : 1, m2 = t2[0] != t2[1] ? 2 : 1;
-    int n = 0;
-    for (int a = 0; a < m0; ++a)
-        for (int b = 0; b < m1; ++b)
-            for (int c = 0; c < m2; ++c) {
-                const int tile = (t0[a] * P.nt1 + t1[b]) * P.nt2 + t2[c];
-                keys[n++] = (uint32_t)(tile * P.G + pt.group);
-            }
-    return n;
+    K.a0 = axis_foot(pt.k0, pt.r0, P.size0); K.a1 = axis_foot(pt.k1, pt.r1, P.size1); K.a2 = axis_foot(pt.k2, pt.r2, P.size2);
+    K.t0[0] = K.a0.lo >> P.s0; K.t0[1] = K.a0.hi >> P.s0;
+    K.t1[0] = K.a1.lo >> P.s1; K.t1[1] = K.a1.hi >> P.s1;
+    K.t2[0] = K.a2.lo >> P.s2; K.t2[1] = K.a2.hi >> P.s2;
+    const bool m0 = K.t0[0] != K.t0[1], m1 = K.t1[0] != K.t1[1], m2 = K.t2[0] != K.t2[1];
+    K.mask = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int a = j >> 2, b = (j >> 1) & 1, c = j & 1;
+        const bool valid = (a == 0 || m0) && (b == 0 || m1) && (c == 0 || m2);
+        K.key[j] = (uint32_t)(((K.t0[a] * P.nt1 + K.t1[b]) * P.nt2 + K.t2[c]) * P.G + pt.group);
+        K.mask |= valid ? 1u << j : 0u;
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -237,12 +244,30 @@ constexpr int HS_BITS = 8;
 constexpr int HS = 1 << HS_BITS;
 constexpr uint32_t EMPTY = 0xffffffffu;
 
-__device__ __forceinline__ int hash_insert(uint32_t *hkey, int *hcnt, uint32_t key, int &rank)
+// The table pays when the keys of a block repeat (neighbouring pixels of a real scene share their tiles: tens of points
+// per key).  A block of unrelated depths brings ~450 distinct keys for 256 slots: past HS_FILL claimed slots no new key
+// is taken in (a key that is not found goes to the global counters directly, which is all the table could have done for
+// it), so probe chains stay short; a wave runs the probe loop as long as its slowest lane.
+#ifndef HS_FILL_DEF
+#define HS_FILL_DEF (HS / 2)
+#endif
+#ifndef HS_PROBES_DEF
+#define HS_PROBES_DEF 8
+#endif
+constexpr int HS_FILL = HS_FILL_DEF, HS_PROBES = HS_PROBES_DEF;
+
+__device__ __forceinline__ int hash_insert(uint32_t *hkey, int *hcnt, int *hfill, uint32_t key, int &rank)
 {
     uint32_t h = (key * 2654435761u) >> (32 - HS_BITS);
-    for (int probe = 0; probe < 24; ++probe) {
-        const uint32_t prev = atomicCAS(&hkey[h], EMPTY, key);
-        if (prev == EMPTY || prev == key) { rank = atomicAdd(&hcnt[h], 1); return (int)h; }
+    const bool open = *(volatile int *)hfill < HS_FILL;
+    for (int probe = 0; probe < HS_PROBES; ++probe) {
+        uint32_t cur = *(volatile uint32_t *)&hkey[h];
+        if (cur == EMPTY) {
+            if (!open) return -1;
+            cur = atomicCAS(&hkey[h], EMPTY, key);
+            if (cur == EMPTY) { atomicAdd(hfill, 1); cur = key; }
+        }
+        if (cur == key) { rank = atomicAdd(&hcnt[h], 1); return (int)h; }
         h = (h + 1) & (HS - 1);
     }
     return -1;
@@ -349,7 +374,9 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
 {
     __shared__ uint32_t hkey[HS];
     __shared__ int hcnt[HS];
+    __shared__ int hfill;
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
+    if (threadIdx.x == 0) hfill = 0;
     __syncthreads();
     const long long idx = point_index<FRONT>(P, BIN_THREADS);
     if (idx >= 0) {
@@ -375,12 +402,14 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
             P.pts[idx] = r;
         }
         if (ok) {
-            uint32_t keys[8];
-            const int n = point_keys(P, pt, keys);
-            for (int i = 0; i < n; ++i) {
-                int rank;
-                if (hash_insert(hkey, hcnt, keys[i], rank) < 0) atomicAdd(&P.cursor[keys[i]], 1);
-            }
+            TileKeys K;
+            point_keys8(P, pt, K);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (K.mask & (1u << j)) {
+                    int rank;
+                    if (hash_insert(hkey, hcnt, &hfill, K.key[j], rank) < 0) atomicAdd(&P.cursor[K.key[j]], 1);
+                }
         }
     }
     if (FRONT == 0) {
@@ -417,14 +446,16 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
 {
     __shared__ uint32_t hkey[HS];
     __shared__ int hcnt[HS];
+    __shared__ int hfill;
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
+    if (threadIdx.x == 0) hfill = 0;
     __syncthreads();
     const long long idx = point_index<FRONT>(P, BIN_THREADS);
     Point pt; uint32_t aux = 0;
     uint32_t xaux[MAX_EXTRA_MAPS] = {0u, 0u, 0u};
-    uint32_t keys[8];
+    TileKeys K;
+    K.mask = 0u;
     int slot[8], rank[8];
-    int n = 0;
     uint4 r = make_uint4(0u, 0xffffffffu, 0u, 0u);
     bool ok = false;
     if (FRONT == 0) {
@@ -455,37 +486,37 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
         if (ok) r = make_record(pt);
     }
     if (ok) {
-        n = point_keys(P, pt, keys);
-        for (int i = 0; i < n; ++i) slot[i] = hash_insert(hkey, hcnt, keys[i], rank[i]);
+        point_keys8(P, pt, K);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (K.mask & (1u << j)) slot[j] = hash_insert(hkey, hcnt, &hfill, K.key[j], rank[j]);
     }
     __syncthreads();
     // one returning global atomic per distinct bucket of this block; hcnt becomes the base
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS)
         if (hkey[s] != EMPTY) hcnt[s] = atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
     __syncthreads();
-    if (n > 0) {
-        if (P.meta) {
-            // tile-local records for the all-integer tile kernels: same enumeration of the <= 8 tiles as point_keys
-            const AxisFoot a0 = axis_foot(pt.k0, pt.r0, P.size0), a1 = axis_foot(pt.k1, pt.r1, P.size1), a2 = axis_foot(pt.k2, pt.r2, P.size2);
-            const int t0[2] = {a0.lo >> P.s0, a0.hi >> P.s0}, t1[2] = {a1.lo >> P.s1, a1.hi >> P.s1}, t2[2] = {a2.lo >> P.s2, a2.hi >> P.s2};
-            const int m0 = t0[0] != t0[1] ? 2 : 1, m1 = t1[0] != t1[1] ? 2 : 1, m2 = t2[0] != t2[1] ? 2 : 1;
-            int i = 0;
-            for (int a = 0; a < m0; ++a)
-                for (int b = 0; b < m1; ++b)
-                    for (int c = 0; c < m2; ++c, ++i) {
-                        const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
-                        P.rec[pos] = make_meta_record(pt, a0, a1, a2, t0[a] << P.s0, t1[b] << P.s1, t2[c] << P.s2, P.s0, P.s1, P.s2, aux);
-                    }
-        } else {
-            for (int i = 0; i < n; ++i) {
-                const int pos = slot[i] >= 0 ? hcnt[slot[i]] + rank[i] : atomicAdd(&P.cursor[keys[i]], 1);
-                P.rec[pos] = r;
-                if (P.feat_kind != MF_FEAT_ONES) P.aux[pos] = aux;
-                if (FRONT == 0)
-                    for (int m = 0; m < P.n_extra; ++m)
-                        if (P.extra[m].aux) P.extra[m].aux[pos] = xaux[m];
+    if (K.mask) {
+        // positions first (the returning atomics of the buckets that are not in the table all in flight), then the stores
+        int pos[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (K.mask & (1u << j)) pos[j] = slot[j] >= 0 ? hcnt[slot[j]] + rank[j] : atomicAdd(&P.cursor[K.key[j]], 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (K.mask & (1u << j)) {
+                if (P.meta) {      // tile-local records for the all-integer tile kernels (no separate class-id word)
+                    const int a = j >> 2, b = (j >> 1) & 1, c = j & 1;
+                    P.rec[pos[j]] = make_meta_record(pt, K.a0, K.a1, K.a2, K.t0[a] << P.s0, K.t1[b] << P.s1, K.t2[c] << P.s2,
+                                                     P.s0, P.s1, P.s2, aux);
+                } else {
+                    P.rec[pos[j]] = r;
+                    if (P.feat_kind != MF_FEAT_ONES) P.aux[pos[j]] = aux;
+                    if (FRONT == 0)
+                        for (int m = 0; m < P.n_extra; ++m)
+                            if (P.extra[m].aux) P.extra[m].aux[pos[j]] = xaux[m];
+                }
             }
-        }
     }
 }
 
