@@ -17,6 +17,9 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $
 echo "tcc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_single -o runc -- python3 tools/bench_single.py 48 > $out/single_frame_updates.jsonl 2> $out/kt_single.err || exit 1
 echo "single-frame trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_maps -o runc -- python3 tools/bench_maps.py 120 shared > $out/shared_frame_under_kt.jsonl 2> $out/kt_maps.err || exit 1
+python3 tools/bench_maps.py 300 > $out/shared_frame_updates.jsonl 2>> $out/kt_maps.err || exit 1
+echo "three-map step done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/sq -o runc -- python3 bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline --no-pipeline > /dev/null 2> $out/sq.err || exit 1
 python3 tools/pmc_summary.py $out/sq mf:: > $out/sq_summary.txt
 echo "sq done"
@@ -39,6 +42,8 @@ cp $outb/sq_summary.txt gpurun_out/prof_summary/${1:-r03}_room_sq_counters.txt
 rm -rf $outb
 cp $out/bench_under_kt.json gpurun_out/prof_summary/${1:-r03}_bench_under_rocprof.json
 cp $out/single_frame_updates.jsonl gpurun_out/prof_summary/${1:-r03}_single_frame_updates.jsonl
+cp $out/shared_frame_updates.jsonl gpurun_out/prof_summary/${1:-r03}_three_map_step.jsonl
+cp $out/kt_maps/runc/*_kernel_stats.csv gpurun_out/prof_summary/${1:-r03}_three_map_step_kernel_stats.csv 2>/dev/null || cp $(find $out/kt_maps -name "*kernel_stats.csv" | head -1) gpurun_out/prof_summary/${1:-r03}_three_map_step_kernel_stats.csv
 cp $out/sq_summary.txt gpurun_out/prof_summary/${1:-r03}_sq_counters.txt
 rm -rf $out
 du -sh gpurun_out/prof_summary; ls gpurun_out/prof_summary
