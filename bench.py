@@ -297,7 +297,7 @@ def recorded_traffic(key):
     if t.get("kernel_sources_sha16") != sources_sha():
         return None, (f"profiles/traffic.json was measured on kernel sources {t.get('kernel_sources_sha16')}, "
                       f"this run uses {sources_sha()}: not reported")
-    return t.get(key), t.get("_source")
+    return t.get(key), t.get(key + "_source", t.get("_source"))
 
 
 def timed_fuse(lay, poses, depth, label, sequential, steps, warmup):

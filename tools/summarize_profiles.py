@@ -106,7 +106,7 @@ fuse = [v for k, v in summary.items() if k.startswith(fuse_kernel)]
 traffic["kernel_sources_sha16"] = bench.sources_sha()
 traffic[workload_key] = fuse[0]["hbm_bytes_per_launch"] if fuse else None
 traffic[workload_key + "_pipeline"] = total
-traffic["_source"] = (f"profiles/{tag}_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+traffic[workload_key + "_source"] = traffic["_source"] = (f"profiles/{tag}_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                       "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 FETCH_SIZE correction of "
                       "/opt/skills/guides/MI355X_MICROARCH.md)")
 with open(tfile, "w") as f:
