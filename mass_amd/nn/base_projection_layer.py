@@ -81,7 +81,7 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         return self.get_feature_map()
 
     # ----------------------------------------------------------------- update
-    def _poses(self, position, yaw, elevation):
+    def _poses(self, position, yaw, elevation, cache=True):
         """Host-side pose math with the reference's torch ops on the CPU
         (projection.py:29-31,104-105; base_projection_layer.py:330-331), so the
         device never evaluates sin/cos and the rotation is bit-identical to the
@@ -95,7 +95,7 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         yaw = torch.as_tensor(yaw, dtype=torch.float32, device='cpu').reshape(-1)
         elevation = torch.as_tensor(elevation, dtype=torch.float32, device='cpu').reshape(-1)
         key = None
-        if position.shape[0] == 1:
+        if cache and position.shape[0] == 1:
             key = (self.data.device, *position[0].tolist(), float(yaw[0]), float(elevation[0]))
             hit = _POSE_CACHE.get("key") == key
             if hit:

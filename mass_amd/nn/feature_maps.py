@@ -51,10 +51,10 @@ def _geometry_stamp(lay):
     return (r.data_ptr(), r._version, x.data_ptr(), x._version, y.data_ptr(), y._version, z.data_ptr(), z._version)
 
 
-def _same_geometry(a, b) -> bool:
+def _same_geometry(a, b, stamp_a=None) -> bool:
     """Equal voxel edges and camera rays, by value (looked at once per version of the tensors: reset()
     rewrites the edges)."""
-    key = (_geometry_stamp(a), _geometry_stamp(b))
+    key = (stamp_a or _geometry_stamp(a), _geometry_stamp(b))
     hit = _SAME_GEOMETRY.get(key)
     if hit is None:
         ta, tb = [(l.rays, l.bins_x, l.bins_y, l.bins_z) for l in (a, b)]
@@ -87,10 +87,14 @@ def update_feature_maps(feature_maps: Union[Mapping[str, Any], Sequence[Any]],
 
     group: List[Any] = []
     if shared:
+        lead_stamp = None
         for lay in layers:
             if (len(group) < _lib.MAX_MAPS_PER_CALL and isinstance(lay, BaseProjectionLayer) and _plain_update(lay) and
-                    lay.data.is_cuda and all(lay is not g for g in group) and (not group or _same_geometry(group[0], lay))):
+                    lay.data.is_cuda and all(lay is not g for g in group) and
+                    (not group or _same_geometry(group[0], lay, lead_stamp))):
                 group.append(lay)
+                if lead_stamp is None:
+                    lead_stamp = _geometry_stamp(lay)
     if len(group) < 2:
         group = []
 
@@ -110,7 +114,7 @@ def update_feature_maps(feature_maps: Union[Mapping[str, Any], Sequence[Any]],
             return uploaded[key]
 
         depth = on_device("depth")
-        poses = lead._poses(observations["position"], observations["yaw"], observations["elevation"])
+        poses = lead._poses(observations["position"], observations["yaw"], observations["elevation"], cache=False)
         updates = []
         for lay in group:
             features, status = None, None

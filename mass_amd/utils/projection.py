@@ -307,19 +307,38 @@ def fuse_frame_maps(updates, sequential=True, min_ray_depth=0.0, max_ray_depth=1
     grids, frames = (_lib.MfGrid * n)(), (_lib.MfFrames * n)()
     weights, wptrs, wbytes = (_lib.c_float * n)(), (_lib.c_void_p * n)(), (_lib.c_size_t * n)()
     keep, spaces = [], []
+    # what all maps share of the frames block
+    fr = frames[0]
+    fr.struct_size = ctypes.sizeof(_lib.MfFrames)
+    fr.n_frames, fr.height, fr.width = B, H, W
+    fr.cam_rays, fr.poses, fr.depth = cam.data_ptr(), poses.data_ptr(), depth.data_ptr()
+    fr.min_depth, fr.max_depth = float(min_ray_depth), float(max_ray_depth)
+    fr.poses_on_host = 0 if poses.is_cuda else 1
+    G = B if sequential else 1
     for m, u in enumerate(updates):
-        fm = _check_map(u["feature_map"])
-        C = fm.shape[-1]
+        fm, bx, by, bz = u["feature_map"], u["bins_x"], u["bins_y"], u["bins_z"]
+        # the grid block of a map is rebuilt (and its tensors looked at) only when one of its tensors is another one
+        gkey = (fm.data_ptr(), bx.data_ptr(), by.data_ptr(), bz.data_ptr(), fm.shape, fm.dtype, bx.dtype, by.dtype, bz.dtype)
+        g = _GRID_BLOCKS.get(gkey)
+        if g is None:
+            fm4 = _check_map(fm)
+            if not (bx.dtype == by.dtype == bz.dtype == torch.float32 and bx.is_contiguous() and by.is_contiguous() and bz.is_contiguous()):
+                raise ValueError("bin edges must be contiguous float32 tensors")
+            require_device(bx, by, bz)
+            g = _grid_struct(fm4, bx, by, bz)
+            if len(_GRID_BLOCKS) > 64:
+                _GRID_BLOCKS.clear()
+            _GRID_BLOCKS[gkey] = g
+        grids[m] = g
+        C = g.channels
         kind, feat = _feature_kind(u.get("features"), C)
+        if m > 0:
+            frames[m] = frames[0]
         fr = frames[m]
-        fr.struct_size = ctypes.sizeof(_lib.MfFrames)
-        fr.n_frames, fr.height, fr.width = B, H, W
-        fr.cam_rays, fr.poses, fr.depth = cam.data_ptr(), poses.data_ptr(), depth.data_ptr()
-        fr.min_depth, fr.max_depth = float(min_ray_depth), float(max_ray_depth)
-        fr.poses_on_host = 0 if poses.is_cuda else 1
         fr.feat_kind = kind
         status = u.get("label_status")
         fr.label_status = status.data_ptr() if status is not None else None
+        fr.feat, fr.feat_height, fr.feat_width = None, 0, 0
         if feat is not None:
             require_device(feat)
             if kind == _lib.FEAT_DENSE_F32:
@@ -328,18 +347,7 @@ def fuse_frame_maps(updates, sequential=True, min_ray_depth=0.0, max_ray_depth=1
                 feat = feat.reshape(B, feat.shape[-2], feat.shape[-1])
             fr.feat_height, fr.feat_width = feat.shape[1], feat.shape[2]
             fr.feat = feat.data_ptr()
-        bx, by, bz = u["bins_x"], u["bins_y"], u["bins_z"]
-        if not (bx.dtype == by.dtype == bz.dtype == torch.float32 and bx.is_contiguous() and by.is_contiguous() and bz.is_contiguous()):
-            bx, by, bz = _f32c(bx), _f32c(by), _f32c(bz)
-        require_device(bx, by, bz)
-        g = grids[m]
-        g.struct_size = ctypes.sizeof(_lib.MfGrid)
-        g.size0, g.size1, g.size2, g.channels = fm.shape
-        g.bins_x, g.bins_y, g.bins_z = bx.data_ptr(), by.data_ptr(), bz.data_ptr()
-        g.n_edges_x, g.n_edges_y, g.n_edges_z = bx.numel(), by.numel(), bz.numel()
-        g.map = fm.data_ptr()
-        G = B if sequential else 1
-        wkey = (g.size0, g.size1, g.size2, g.channels, B * H * W, G)
+        wkey = (g.size0, g.size1, g.size2, C, B * H * W, G)
         need = _WORKSPACE_BYTES.get(wkey)
         if need is None:
             need = lib.mf_fuse_workspace_bytes(g, B * H * W, G)
@@ -355,12 +363,13 @@ def fuse_frame_maps(updates, sequential=True, min_ray_depth=0.0, max_ray_depth=1
         wp, wb = ws.get(need, fm.device)
         weights[m] = float(u.get("interpolation_weight", 0.5))
         wptrs[m], wbytes[m] = wp.value, wb
-        keep.append((feat, bx, by, bz))
+        keep.append((feat, fm, bx, by, bz))
     check(lib.mf_fuse_frame_maps(grids, frames, weights, n, _lib.MODE_SEQUENTIAL if sequential else _lib.MODE_MERGED,
                                  wptrs, wbytes, current_stream(u0["feature_map"].device)))
 
 
 _WORKSPACE_BYTES = {}      # (map shape, points, groups) -> mf_fuse_workspace_bytes (a pure function of them)
+_GRID_BLOCKS = {}          # (pointers, shape, dtypes of a map and its edges) -> checked mf_grid block
 
 
 class FusePipeline:
