@@ -19,8 +19,9 @@
 //                  binned pixel is written out for step 3;
 //   2. scan      : exclusive prefix sum of the bucket sizes; list of non-empty tiles in eight load
 //                  classes, heaviest first; the call's density picks the tile kernel;
-//   3. scatter   : writes the 20-byte point record of every (pixel, tile) pair into its bucket
-//                  slot (slot = bucket base + LDS-local rank);
+//   3. scatter   : writes the point record (16 bytes, + a 4-byte class id / feature index where the record
+//                  format has no room for it) of every (pixel, tile) pair into its bucket slot
+//                  (slot = bucket base + LDS-local rank);
 //   4. tile kernel, one of
 //        fuse_cells_kernel   sequential frames of class ids / ones, sparse (a batch of unrelated frames): all
 //                  frames of a 4 x 4 x 8 tile at once through compact (voxel, frame) cells, integer sums
@@ -40,6 +41,12 @@
 //        fuse_single_kernel / fuse_single_dense_kernel   single-group calls: one pass, integer sums.
 // No global float atomics are used (guide: ~1.3 TB/s, 17x slower when scattered); HBM sees each
 // tile once per call, coalesced along z.
+//
+// mf_fuse_frame_maps (the agent's loop over its maps per simulator step, navigation_policy.py:164-171): steps 1-3 do
+// not depend on the features, so a single group is bucketed ONCE for up to four maps that share grid and frames
+// (count_kernel also checks the other maps' class ids, finds their feature range and zeroes their counters;
+// tile_list_kernel makes one list per map; scatter_kernel writes one aux word per record and map), and the maps'
+// tile kernels run side by side (MultiCtx, map_streams).
 //
 // Tuning / diagnostics, all off by default and range-checked (env_int): MF_TILE="s0 s1 s2 threads [gc]"
 // overrides the tile shape of fuse_tiles_kernel, MF_DENSE=0 keeps calls off the 4 x 4 x 8 integer kernels,
