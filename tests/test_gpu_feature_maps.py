@@ -192,3 +192,88 @@ def test_full_size_frame_three_maps(device):
         loop_update(b, o)
     for name in a:
         assert torch.equal(a[name].data, b[name].data), name      # single-pass integer kernels: identical bits
+
+
+def test_merged_batch_of_frames_onto_two_maps(device):
+    """MF_MODE_MERGED with several frames is one group as well: bucketed once for both maps (the functional API's
+    batch semantics), equal to a merged fuse_frames call per map."""
+    from mass_amd.utils.projection import fuse_frame_maps, fuse_frames, Workspace
+    H, W, M, C_sem, n = 48, 64, 32, 6, 4
+    a, b = make_layers(device, H, W, M, C_sem), make_layers(device, H, W, M, C_sem)
+    fr = frames(n, H, W, C_sem, 3, seed=15)
+    lead = a["occupancy"]
+    poses = lead._poses(fr["position"], fr["yaw"], fr["elevation"])
+    depth = fr["depth"].to(device)
+    labels = fr["semantic"][..., 0].to(device)
+    ups = []
+    for name, feats in (("occupancy", None), ("semantic", labels)):
+        lay = a[name]
+        ups.append(dict(bins_x=lay.bins_x, bins_y=lay.bins_y, bins_z=lay.bins_z, features=feats, feature_map=lay.data,
+                        interpolation_weight=lay.interpolation_weight, workspace=Workspace()))
+    ups[0].update(cam_rays=lead.rays, poses=poses, depth=depth)
+    fuse_frame_maps(ups, sequential=False)
+    for name, feats in (("occupancy", None), ("semantic", labels)):
+        lay = b[name]
+        fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, feats, lay.data,
+                    interpolation_weight=lay.interpolation_weight, sequential=False, workspace=Workspace())
+        same(a[name].data, b[name].data, name)
+        assert int((b[name].data != 0).sum()) > 0
+    # a sequential batch of several frames is not one group: the call issues it map after map, same results
+    for name in ("occupancy", "semantic"):
+        a[name].reset(); b[name].reset()
+    fuse_frame_maps(ups, sequential=True)
+    for name, feats in (("occupancy", None), ("semantic", labels)):
+        lay = b[name]
+        fuse_frames(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth, feats, lay.data,
+                    interpolation_weight=lay.interpolation_weight, sequential=True, workspace=Workspace())
+        same(a[name].data, b[name].data, name + " sequential")
+
+
+def test_arguments_the_shared_call_refuses(device):
+    """Error behaviour of mf_fuse_frame_maps: maps of different size, the same map twice, too many maps, a workspace
+    shared by two maps (the Python mirror), frames that differ in more than their features (C ABI)."""
+    import ctypes
+    from mass_amd import _lib
+    from mass_amd.utils.projection import fuse_frame_maps, Workspace
+    H, W = 48, 64
+    a = make_layers(device, H, W, 32, 5)
+    small = make_layers(device, H, W, 16, 5)["occupancy"]
+    fr = frames(1, H, W, 5, 3, seed=3)
+    lead = a["occupancy"]
+    poses, depth = lead._poses(fr["position"][0], fr["yaw"][0], fr["elevation"][0]), fr["depth"].to(device)
+
+    def upd(lay, feats=None, ws=None):
+        return dict(bins_x=lay.bins_x, bins_y=lay.bins_y, bins_z=lay.bins_z, features=feats, feature_map=lay.data,
+                    interpolation_weight=0.5, workspace=ws or Workspace(), cam_rays=lead.rays, poses=poses, depth=depth)
+    before = lead.data.clone()
+    with pytest.raises(ValueError, match="share their voxel grid"):
+        fuse_frame_maps([upd(lead), upd(small)])
+    with pytest.raises(ValueError, match="same buffer"):
+        fuse_frame_maps([upd(lead), upd(lead)])
+    with pytest.raises(ValueError, match="maps per call"):
+        fuse_frame_maps([upd(lead)] * 5)
+    shared_ws = Workspace()
+    with pytest.raises(ValueError, match="Workspace of its own"):
+        fuse_frame_maps([upd(lead, ws=shared_ws), upd(a["rgb"], fr["rgb"][0].to(device), ws=shared_ws)])
+    assert torch.equal(lead.data, before)                       # nothing was issued
+    # C ABI: the frames blocks of one call may differ in their features only
+    from mass_amd.utils.projection import _frames_call
+    g0, f0, *_ = _frames_call(lead.bins_x, lead.bins_y, lead.bins_z, lead.rays, poses, depth, None, lead.data, 0.0, 10.0, None)
+    sem = a["semantic"]
+    labels = fr["semantic"][0, ..., 0].to(device)
+    g1, f1, *_ = _frames_call(sem.bins_x, sem.bins_y, sem.bins_z, sem.rays, poses, depth, labels, sem.data, 0.0, 10.0, None)
+    f1.feat = labels.data_ptr()
+    f0.n_frames = f1.n_frames = 1
+    f0.poses = f1.poses = poses.data_ptr(); f0.depth = f1.depth = depth.data_ptr()
+    f1.cam_rays = f0.cam_rays
+    f1.max_depth = 5.0                                          # ... not in the depth range
+    grids, frs = (_lib.MfGrid * 2)(g0, g1), (_lib.MfFrames * 2)(f0, f1)
+    w = [Workspace(), Workspace()]
+    need = [_lib.lib.mf_fuse_workspace_bytes(g, H * W, 1) for g in (g0, g1)]
+    got = [w[i].get(need[i], device) for i in range(2)]
+    wp = (_lib.c_void_p * 2)(got[0][0].value, got[1][0].value)
+    wb = (_lib.c_size_t * 2)(got[0][1], got[1][1])
+    rc = _lib.lib.mf_fuse_frame_maps(grids, frs, (_lib.c_float * 2)(0.5, 0.5), 2, _lib.MODE_SEQUENTIAL, wp, wb,
+                                     _lib.current_stream(device))
+    assert rc == _lib.MF_ERR_INVALID and b"more than its features" in _lib.lib.mf_last_error()
+    assert torch.equal(lead.data, before)
