@@ -14,7 +14,12 @@
  *     library allocates no persistent device memory.
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work
  *     is enqueued on it and nothing synchronises.  Calls that touch the same
- *     map / workspace must be stream-ordered by the caller.
+ *     map / workspace must be stream-ordered by the caller.  The device of
+ *     `stream` is the calling thread's current device (hipSetDevice), as for a
+ *     kernel launch: one process per GPU is the model.
+ *     mf_fuse_frame_maps is the one call that uses streams of its own beside
+ *     `stream` (kept per host thread and device, forked from and joined into
+ *     `stream` inside the call).
  *   - return value: MF_OK (0) or a negative MF_ERR_* code; the message is
  *     available from mf_last_error() (thread local).  No C++ exception crosses
  *     the ABI.
