@@ -152,6 +152,19 @@ __device__ __forceinline__ uint32_t read_label(const void *feat, int kind, long 
     return (v < 0 || v > 0x7fffffffLL) ? 0xffffffffu : (uint32_t)v;
 }
 
+// Pixel (y, x) of the frame a block works on (front end 0: blocks own 16 x 16 patches, so row and column come
+// from the block and thread index: no division by the image width).
+struct Pix { int y, x; };
+__device__ __forceinline__ Pix patch_pixel(const FuseParams &P);
+
+// Index of the feature pixel under frame pixel (y, x) of frame f: features may be coarser than the frame by whole
+// factors (repeat_interleave upsampling, base_projection_layer.py:322-325); the usual factor 1 takes no division.
+__device__ __forceinline__ long long feature_pixel(int f, int y, int x, int fh, int fw, int rep_y, int rep_x)
+{
+    if (rep_y != 1 || rep_x != 1) { y /= rep_y; x /= rep_x; }       // (uniform)
+    return ((long long)f * fh + y) * fw + x;
+}
+
 // Front end 0: pixel of a posed frame -> binned point (a3 + a4).
 // Front end 1: already binned point arrays (functional update_feature_map).
 template <int FRONT>
@@ -174,12 +187,12 @@ __device__ __forceinline__ bool get_point(const FuseParams &P, long long idx, Po
         const bool ok = bin_point(P.bins, p0, p1, p2, d, P.min_d, P.max_d, kx, ky, kz, rx, ry, rz);
         pt.k0 = ky; pt.k1 = kx; pt.k2 = kz; pt.r0 = ry; pt.r1 = rx; pt.r2 = rz;
         pt.group = P.G == 1 ? 0 : f;
-        // the class id is also read for pixels that miss the map when ids are being checked: the
-        // reference's one_hot looks at every pixel (semantic_projection_layer.py:203-209)
-        if ((ok || P.label_status) && P.feat_kind != MF_FEAT_ONES) {
-            const int y = pix / P.W, x = pix - y * P.W;
-            const long long fi = ((long long)f * P.fh + y / P.rep_y) * P.fw + x / P.rep_x;
-            aux = P.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)fi : read_label(P.feat, P.feat_kind, fi);
+        // The class id is read here only when ids are being checked, then for every pixel, also one that misses the
+        // map: the reference's one_hot looks at the whole image (semantic_projection_layer.py:203-209).
+        // (scatter_kernel reads the word that goes with the record itself.)
+        if (P.label_status && P.feat_kind >= MF_FEAT_LABEL_U8 && P.feat_kind <= MF_FEAT_LABEL_I64) {
+            const Pix px = patch_pixel(P);
+            aux = read_label(P.feat, P.feat_kind, feature_pixel(f, px.y, px.x, P.fh, P.fw, P.rep_y, P.rep_x));
         }
         return ok;
     } else {
@@ -212,6 +225,16 @@ __device__ __forceinline__ long long point_index(const FuseParams &P, int thread
     }
     const long long idx = (long long)blockIdx.x * threads + threadIdx.x;
     return idx < P.n_points ? idx : -1;
+}
+
+__device__ __forceinline__ Pix patch_pixel(const FuseParams &P)
+{
+    const int pw = (P.W + PATCH - 1) / PATCH;
+    const int py = blockIdx.x / pw, px = blockIdx.x - py * pw;       // (scalar: once per block)
+    Pix p;
+    p.y = py * PATCH + (int)(threadIdx.x / PATCH);
+    p.x = px * PATCH + (int)(threadIdx.x % PATCH);
+    return p;
 }
 
 // The <= 8 (tile, group) buckets a point's footprint overlaps, at fixed positions: key[4 a + 2 b + c] for the lower / upper tile per axis, bit j of the result set
@@ -404,9 +427,8 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
             for (int m = 0; m < P.n_extra; ++m) {       // class ids of the further maps: every pixel is looked at, as above
                 const FuseParams::ExtraMap &E = P.extra[m];
                 if (!E.label_status || E.feat_kind < MF_FEAT_LABEL_U8 || E.feat_kind > MF_FEAT_LABEL_I64) continue;
-                const int pix = (int)(idx - (long long)blockIdx.y * (P.H * P.W));
-                const int y = pix / P.W, x = pix - y * P.W;
-                const long long fi = ((long long)blockIdx.y * E.fh + y / E.rep_y) * E.fw + x / E.rep_x;
+                const Pix px = patch_pixel(P);
+                const long long fi = feature_pixel((int)blockIdx.y, px.y, px.x, E.fh, E.fw, E.rep_y, E.rep_x);
                 if (read_label(E.feat, E.feat_kind, fi) >= (uint32_t)E.C) { *E.label_status = 1; *E.abort = 1; }
             }
         }
@@ -441,9 +463,8 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
             const int ry = m < 0 ? P.rep_y : P.extra[m].rep_y, rx = m < 0 ? P.rep_x : P.extra[m].rep_x;
             unsigned mx = 0u;
             if (idx >= 0) {
-                const int pix = (int)(idx - (long long)blockIdx.y * (P.H * P.W));
-                const int y = pix / P.W, x = pix - y * P.W;
-                const float *row = f + (((long long)blockIdx.y * fh + y / ry) * fw + x / rx) * Cm;
+                const Pix px = patch_pixel(P);
+                const float *row = f + feature_pixel((int)blockIdx.y, px.y, px.x, fh, fw, ry, rx) * Cm;
                 for (int c = 0; c < Cm; ++c) mx = max(mx, __float_as_uint(row[c]) & 0x7fffffffu);
             }
             for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_down((int)mx, o, 64));
@@ -480,18 +501,15 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
             pt.k0 = r.x & 1023; pt.k1 = (r.x >> 10) & 1023; pt.k2 = (r.x >> 20) & 1023;
             pt.r0 = __uint_as_float(r.y & rm); pt.r1 = __uint_as_float(r.z & rm); pt.r2 = __uint_as_float(r.w & rm);
             pt.group = P.G == 1 ? 0 : (int)blockIdx.y;
+            const Pix px = patch_pixel(P);
             if (P.feat_kind != MF_FEAT_ONES) {
-                const int pix = (int)(idx - (long long)blockIdx.y * (P.H * P.W));
-                const int y = pix / P.W, x = pix - y * P.W;
-                const long long fi = ((long long)blockIdx.y * P.fh + y / P.rep_y) * P.fw + x / P.rep_x;
+                const long long fi = feature_pixel((int)blockIdx.y, px.y, px.x, P.fh, P.fw, P.rep_y, P.rep_x);
                 aux = P.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)fi : read_label(P.feat, P.feat_kind, fi);
             }
             for (int m = 0; m < P.n_extra; ++m) {
                 const FuseParams::ExtraMap &E = P.extra[m];
                 if (!E.aux) continue;
-                const int pix = (int)(idx - (long long)blockIdx.y * (P.H * P.W));
-                const int y = pix / P.W, x = pix - y * P.W;
-                const long long fi = ((long long)blockIdx.y * E.fh + y / E.rep_y) * E.fw + x / E.rep_x;
+                const long long fi = feature_pixel((int)blockIdx.y, px.y, px.x, E.fh, E.fw, E.rep_y, E.rep_x);
                 xaux[m] = E.feat_kind == MF_FEAT_DENSE_F32 ? (uint32_t)fi : read_label(E.feat, E.feat_kind, fi);
             }
         }
