@@ -277,3 +277,42 @@ def test_arguments_the_shared_call_refuses(device):
                                      _lib.current_stream(device))
     assert rc == _lib.MF_ERR_INVALID and b"more than its features" in _lib.lib.mf_last_error()
     assert torch.equal(lead.data, before)
+
+
+def test_two_host_threads_each_with_their_own_maps(device):
+    """The side streams of the shared call are kept per host thread: two threads, each on a stream of its own, update
+    their own sets of maps at the same time (ctypes drops the GIL inside the library) and get what a serial run gives."""
+    import threading
+    from mass_amd.nn.feature_maps import update_feature_maps
+    H, W, M, C_sem, n = 48, 64, 32, 5, 6
+    sets = [make_layers(device, H, W, M, C_sem) for _ in range(2)]
+    refs = [make_layers(device, H, W, M, C_sem) for _ in range(2)]
+    frs = [frames(n, H, W, C_sem, 3, seed=31 + k) for k in range(2)]
+    obs = [[observation(frs[k], t, device) for t in range(n)] for k in range(2)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream(device)
+            with torch.cuda.stream(stream):
+                for rep in range(3):
+                    for o in obs[k]:
+                        update_feature_maps(sets[k], o, validate="defer")
+            stream.synchronize()
+        except Exception as exc:                     # noqa: BLE001 (reported below, in the main thread)
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for rep in range(3):
+            for o in obs[k]:
+                loop_update(refs[k], o)
+    torch.cuda.synchronize()
+    for k in range(2):
+        for name in sets[k]:
+            same(sets[k][name].data, refs[k][name].data, f"thread {k} {name}")
