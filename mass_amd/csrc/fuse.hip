@@ -136,6 +136,10 @@ struct TileParams {
     const int *active;
     const uint4 *rec;
     const uint32_t *aux;
+    // fuse_wave_kernel (light tiles, one wave each)
+    int *active_rw;            // the work list again, writable: a tile it cannot take is appended to the last load class
+    const int4 *light;         // its work items (tile_list_kernel): {tile, first record, records, origin 10 + 10 + 10 bits}
+    int wave_lds;              // bytes of LDS per wave
 };
 
 struct Point {
@@ -636,6 +640,9 @@ constexpr int MODE_SLOT = ABORT_SLOT + 5;       // which tile kernel takes the c
 constexpr int HINT_SLOT = ABORT_SLOT + 6;       // [2] records listed, non-empty buckets x tile voxels / 2 (diagnostics)
 constexpr int TICKET_DENSE = ABORT_SLOT + 8;    // work counter of fuse_dense_kernel (ticket[0] is fuse_tiles_kernel's)
 constexpr int TICKET_CELLS = ABORT_SLOT + 9;    // work counter of fuse_cells_kernel
+constexpr int LIGHT_COUNT = ABORT_SLOT + 10;    // items of fuse_wave_kernel, one-wave teams (light tiles of a sparse batch)
+constexpr int MEDIUM_COUNT = ABORT_SLOT + 11;   // its items for four-wave teams (medium tiles)
+constexpr int WAVE_REFUSED = ABORT_SLOT + 12;   // tiles it handed on to fuse_cells_kernel (diagnostics)
 constexpr int ABORT_MAPS = 32;                  // [MAX_EXTRA_MAPS] abort words of the further maps of a mf_fuse_frame_maps call
 constexpr int ABSMAX_MAPS = 36;                 // [MAX_EXTRA_MAPS] their FEAT_ABSMAX words
 constexpr int MODE_TILES = 0, MODE_DENSE = 2, MODE_CELLS = 3;
@@ -650,10 +657,13 @@ struct ListMap {
     int *ticket, *active, *items;
     int split_min, split_slots, min_mean, first_ticket, dense_tv, first_ticket_dense, first_ticket_cells;
     const int *abort;              // a class id of this map was out of range
+    int light_max, medium_max;     // tiles of a sparse batch with at most this many records go to fuse_wave_kernel, one wave / four waves per tile (0: none)
+    int4 *light;                   // its work items: [n_tiles] one-wave teams, [n_tiles] four-wave teams
 };
 struct ListParams {
     const int *cursor;             // exclusive offsets
     int n_tiles, G, split_part;
+    int nt1, nt2, s0, s1, s2;      // tile grid (the origin of a light tile rides in its work item)
     const int *nonempty;           // buckets with entries (scan_apply_kernel)
     ListMap map[1 + MAX_EXTRA_MAPS];
 };
@@ -670,16 +680,18 @@ __global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
     const int first_ticket_dense = M.first_ticket_dense, first_ticket_cells = M.first_ticket_cells;
     const int *abort = M.abort;
     const int t = blockIdx.x * 256 + threadIdx.x;
+    // Density of the call: records per non-empty (tile, frame) bucket and tile voxel.  Half a record per
+    // voxel and frame or more is a real scene (a batch of unrelated frames has 0.03): the all-integer
+    // tile kernel takes it when the call was bucketed on its tiles (dense_tv = their voxel count, else 0).
+    // (every thread works the choice out: which list a tile goes to depends on it)
+    const long long total = cursor[n_tiles * G], half = (long long)*nonempty * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
+    // bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is, bits 22 / 23: forced (dev / tests),
+    // bit 24: the records are tile-local (meta format): only these two kernels read them
+    const bool dense_ok = dense_tv & (1 << 20), cells_ok = dense_tv & (1 << 21);
+    const bool dense = dense_ok && !(cells_ok && (dense_tv & (1 << 23))) && (total >= half || (dense_tv & (1 << 22)) || ((dense_tv & (1 << 24)) && !cells_ok));
+    const int tile_mode = dense ? MODE_DENSE : cells_ok ? MODE_CELLS : MODE_TILES;
     if (t == 0) {
-        // Density of the call: records per non-empty (tile, frame) bucket and tile voxel.  Half a record per
-        // voxel and frame or more is a real scene (a batch of unrelated frames has 0.03): the all-integer
-        // tile kernel takes it when the call was bucketed on its tiles (dense_tv = their voxel count, else 0).
-        const long long total = cursor[n_tiles * G], half = (long long)*nonempty * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
-        // bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is, bits 22 / 23: forced (dev / tests),
-        // bit 24: the records are tile-local (meta format): only these two kernels read them
-        const bool dense_ok = dense_tv & (1 << 20), cells_ok = dense_tv & (1 << 21);
-        const bool dense = dense_ok && !(cells_ok && (dense_tv & (1 << 23))) && (total >= half || (dense_tv & (1 << 22)) || ((dense_tv & (1 << 24)) && !cells_ok));
-        ticket[MODE_SLOT] = dense ? MODE_DENSE : cells_ok ? MODE_CELLS : MODE_TILES;
+        ticket[MODE_SLOT] = tile_mode;
         ticket[HINT_SLOT] = (int)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
         ticket[HINT_SLOT + 1] = (int)(half > 0x7fffffffLL ? 0x7fffffffLL : half);
         // every tile kernel deals its first items statically (see there) and has a work counter of its own
@@ -708,8 +720,27 @@ __global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
         for (int p = 0; p < nparts; ++p) { items[2 * (base + p)] = t; items[2 * (base + p) + 1] = p | (nparts << 8) | (slot << 16); }
         return;                                     // nothing is listed for the tile kernel
     }
-    const int cls = tile_class(n);
     const int lane = threadIdx.x & 63;
+    // A sparse batch (fuse_cells_kernel's): its light tiles are work items of fuse_wave_kernel, one wave each.  The item
+    // carries what the wave would otherwise look up in a chain of dependent loads: first record, count, tile origin.
+    if (tile_mode == MODE_CELLS && (M.light_max > 0 || M.medium_max > 0)) {
+#pragma unroll
+        for (int team = 0; team < 2; ++team) {           // 0: one wave per tile, 1: four waves
+            const bool mine = n > 0 && (team == 0 ? n <= M.light_max : n <= M.medium_max);
+            const unsigned long long m = __ballot(mine);
+            if (m == 0) continue;
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&ticket[team == 0 ? LIGHT_COUNT : MEDIUM_COUNT], __popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1, 64);
+            if (mine) {
+                const int tz = t % LP.nt2, ty = (t / LP.nt2) % LP.nt1, tx = t / (LP.nt2 * LP.nt1);
+                M.light[(team == 0 ? 0 : n_tiles) + base + __popcll(m & ((1ull << lane) - 1ull))] =
+                    make_int4(t, cursor[t * G], n, (tx << LP.s0) | ((ty << LP.s1) << 10) | ((tz << LP.s2) << 20));
+                n = 0;                                   // not listed for the tile kernel
+            }
+        }
+    }
+    const int cls = tile_class(n);
     for (int c = 0; c < TILE_CLASSES; ++c) {
         const bool mine = n > 0 && cls == c;
         const unsigned long long m = __ballot(mine);
@@ -2092,6 +2123,367 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
 }
 
 // ----------------------------------------------------------------------------
+// fuse_wave_kernel: the light and medium tiles of a sparse batch, one wave (or one team of four) per tile
+// ----------------------------------------------------------------------------
+// Of the ~100 k tiles a batch of unrelated frames lists, five in six hold at most 512 records (median 136), yet in
+// fuse_cells_kernel each costs a workgroup seven barrier-delimited phases with one or two of its four waves busy, and
+// the 27 KB of deltas per tile hold the CU at twelve waves.  The SIMDs of both kernels are busy issuing instructions
+// ~90 % of the time (SQ_ACTIVE_INST_ANY, profiles/r04_*): what counts is instructions per tile and per record.  Here a
+// TEAM (one wave for tiles of <= 64 RPL records, four waves = one workgroup for tiles of <= 256 RPL) takes a tile:
+//   * the tile's records are decoded ONCE into registers (4 per record: packed coordinates, class id and frame; the three
+//     ratios) and stay there for every pass;
+//   * the mask pass and the scan cover the whole tile; everything after them runs four times, once per SLAB: the 32
+//     voxels whose first two coordinates have parities (p0, p1).  A record's footprint is 2 x 2 x 2, so exactly one
+//     of its four (corner 0, corner 1) pairs falls into a slab: every sweep handles two corners of every record
+//     (the same corner work in all as one sweep over eight), but needs only 32 x C deltas (6.9 KB at C = 54), a quarter
+//     of the cells and a quarter of the rows in registers - 18 KB of LDS per wave, eight waves per CU, and for a one-wave
+//     team no workgroup barrier anywhere (the LDS unit takes one wave's operations in order);
+//   * a slab's four rows are requested at the start of its sweep and combined at its end (old * prod a + D, two floats
+//     per instruction); a float4 whose voxels received nothing is not written back;
+//   * the work items carry first record, count and origin (tile_list_kernel), the next item is fetched a tile ahead
+//     and one word of each of its records is touched, teams take items round-robin (no tickets).
+// All LDS updates are branch-free: a corner outside the tile ORs / adds into a spare word behind the arrays.
+// A tile the team cannot take - a slab needs more cells than fit, or a record's footprint is clamped at the map
+// border (its two corners of an axis are the same voxel: the parity argument fails) - is appended to the last load
+// class of fuse_cells_kernel's list before anything of it is written; that kernel runs behind this one.
+// Arithmetic is fuse_cells_kernel's: integer sums, suffix form, 31-bit deltas.
+constexpr int WAVE_NT = 256;              // four independent waves, or one team of four
+#ifndef WAVE_RPL_DEF
+#define WAVE_RPL_DEF 8
+#endif
+constexpr int WAVE_RPL = WAVE_RPL_DEF;    // records per thread: tiles of up to 512 (one wave) / 2,048 (four waves) records
+constexpr int WAVE_CW1 = 512, WAVE_CW4 = 1152;    // (voxel, frame) cells of a slab that fit: one-wave team, four-wave team
+constexpr int WAVE_SPARE = 64;            // spare words behind each array (targets of the corners outside the tile)
+
+static __host__ __device__ inline size_t wave_lds_bytes(int C, int team)
+{
+    const size_t cw = team == 1 ? WAVE_CW1 : WAVE_CW4;
+    // masks + cell bases (+ spare), prod a, slab totals + flags, cells (W, S2; + spare), deltas (+ spare)
+    return (512 + WAVE_SPARE) * 4 + 128 + 64 + (cw + WAVE_SPARE) * 16 + ((size_t)32 * C + 32) * 4;
+}
+
+template <int TEAM>
+__device__ __forceinline__ void team_sync()
+{
+    if (TEAM == 1) {
+        // one wave: the LDS unit executes its operations in issue order; the compiler must keep that order
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int KIND, int TEAM, int RPL, int F4S>     // F4S: float4s per thread and slab, >= ceil(8 C / (64 TEAM))
+__global__ __launch_bounds__(WAVE_NT, (TEAM == 1 ? 2 : 3)) void fuse_wave_kernel(TileParams P)
+{
+    extern __shared__ float smem[];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int TT = 64 * TEAM, CW = TEAM == 1 ? WAVE_CW1 : WAVE_CW4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = TEAM == 1 ? lane : (int)threadIdx.x;                         // thread of the team
+    const int C = P.C;
+    if (P.ticket[MODE_SLOT] != MODE_CELLS) return;                             // (uniform) not a sparse batch
+    const int n_items = min(P.ticket[TEAM == 1 ? LIGHT_COUNT : MEDIUM_COUNT], P.n_tiles);
+    const int gw = TEAM == 1 ? blockIdx.x * (WAVE_NT / 64) + wave : (int)blockIdx.x;
+    const int NWV = TEAM == 1 ? gridDim.x * (WAVE_NT / 64) : (int)gridDim.x;
+    if (gw >= n_items) return;                                                 // (per team)
+    const int4 *items = P.light + (TEAM == 1 ? 0 : P.n_tiles);
+
+    char *mine = reinterpret_cast<char *>(smem) + (TEAM == 1 ? (size_t)wave * P.wave_lds : 0);
+    unsigned *vm = reinterpret_cast<unsigned *>(mine);                         // [4][128] frame mask 0..31, cell base, mask 32..63, cell base of frame 32; spare
+    float *atot = reinterpret_cast<float *>(vm + 512 + WAVE_SPARE);            // [32] prod a of the slab's voxels
+    int *misc = reinterpret_cast<int *>(atot + 32);                            // [0..3] cells per slab, [4] refuse
+    unsigned long long *Wc = reinterpret_cast<unsigned long long *>(misc + 16);   // [CW + spare] W, then (g, a), then t_f
+    unsigned long long *Sc = Wc + CW + WAVE_SPARE;                             // [CW + spare] S2
+    unsigned *D = reinterpret_cast<unsigned *>(Sc + CW + WAVE_SPARE);          // [32][C] deltas of the slab, units of 2^-CELLS_FX; 32 spare
+    const unsigned n4 = 8u * (unsigned)C;                                      // float4s of a slab (four rows of 2 C)
+    for (int i = t; i < 512 + WAVE_SPARE; i += TT) vm[i] = 0u;
+    for (int i = t; i < 2 * (CW + WAVE_SPARE); i += TT) Wc[i] = 0ull;
+    for (unsigned i = t; i < 32u * C + 32u; i += TT) D[i] = 0u;
+    if (t < 16) misc[t] = 0;
+
+    const int fx_c = 182 - P.fx_shift;
+    const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
+    const float du_inv = __uint_as_float((unsigned)(127 - CELLS_FX) << 23);
+    const float du_scale = __uint_as_float((unsigned)(127 + CELLS_FX) << 23);
+    const float iw = P.iw;
+    // scan (first wave of the team): the lane owns the voxels 2 lane, 2 lane + 1 of the slab-major order (slab = lane / 16)
+    const int nv0 = ((lane >> 5) + 2 * ((lane >> 3) & 1)) * 32 + (((lane >> 4) & 1) + 2 * ((lane >> 2) & 1)) * 8 + 2 * (lane & 3);
+    // final pass: float4 j = t + TT i of a slab: its byte offset in slab (0, 0) from the tile's first voxel, its first
+    // voxel and how many of its four floats belong to that voxel (tile-invariant)
+    const unsigned rsb = (unsigned)P.size2 * (unsigned)C * 4u;                  // bytes between map rows (x + 1)
+    unsigned pk[F4S], offs[F4S];
+#pragma unroll
+    for (int i = 0; i < F4S; ++i) {
+        const unsigned j = t + (unsigned)TT * i, c2 = 2u * C;
+        const unsigned row = (j >= c2) + (j >= 2 * c2) + (j >= 3 * c2), col4 = j - row * c2;
+        const unsigned e = 4u * col4, svr = div_magic(e, P.magicC), rem = e - svr * C;
+        const unsigned cross = min(4u, (unsigned)C - rem);
+        pk[i] = (row * 8u + svr) | (cross << 5) | (row << 8) | ((j < n4 ? 1u : 0u) << 10);
+        offs[i] = ((2u * (row >> 1)) * (unsigned)P.size1 + 2u * (row & 1u)) * rsb + col4 * 16u;
+    }
+
+    // corner weights of a record's pair in the slab: per axis (projection.py:280-316) r < 0.5: (0.5 - r, r + 0.5), else
+    // (1.5 - r, r - 0.5); (w0 * w1) * w2 + 1e-9 in the reference's order (projection.py:319-323)
+    auto pair_weights = [](float r0, float r1, float r2, int ca, int cb, float &wl, float &wh) {
+        const float w0 = ca ? r0 + (r0 < 0.5f ? 0.5f : -0.5f) : (r0 < 0.5f ? 0.5f : 1.5f) - r0;
+        const float w1 = cb ? r1 + (r1 < 0.5f ? 0.5f : -0.5f) : (r1 < 0.5f ? 0.5f : 1.5f) - r1;
+        const float w01 = w0 * w1;
+        wl = 1e-9f + w01 * ((r2 < 0.5f ? 0.5f : 1.5f) - r2);
+        wh = 1e-9f + w01 * (r2 + (r2 < 0.5f ? 0.5f : -0.5f));
+    };
+    auto load_records = [&](int first, int n, uint4 (&raw)[RPL]) {
+#pragma unroll
+        for (int b = 0; b < RPL; ++b) {
+            raw[b] = make_uint4(0u, 0u, 0u, 0u);
+            if (b * TT < n) {                                                   // (uniform)
+                const int k = b * TT + t;
+                raw[b] = P.rec[first + (k < n ? k : n - 1)];
+            }
+        }
+    };
+    int4 item = items[gw];
+    item.y = __builtin_amdgcn_readfirstlane(item.y); item.z = __builtin_amdgcn_readfirstlane(item.z);
+    uint4 raw[RPL];
+    load_records(item.y, item.z, raw);
+    team_sync<TEAM>();                                                          // the zeroed arrays
+
+    for (int it = gw; it < n_items; it += NWV) {
+        const int tile = __builtin_amdgcn_readfirstlane(item.x), n = __builtin_amdgcn_readfirstlane(item.z), n_tile = n;
+        const unsigned org = (unsigned)__builtin_amdgcn_readfirstlane(item.w);
+        const int o0 = org & 1023u, o1 = (org >> 10) & 1023u, o2 = org >> 20;
+        int4 item_n = make_int4(-1, 0, 0, 0);
+        if (it + NWV < n_items) item_n = items[it + NWV];                      // (uniform) lands while the masks are built
+
+        // ---- decode (once per tile) + mask pass
+        unsigned meta[RPL];                                                     // coordinate + 1 of the lower corner (3 + 3 + 4 bits), class id (8), frame (6)
+        float q0[RPL], q1[RPL], q2[RPL];                                        // the three ratios (the weights are worked out where they are used)
+        bool clamped = false;
+#pragma unroll
+        for (int b = 0; b < RPL; ++b) {
+            meta[b] = 15u << 6;                                                 // no record: its corners lie outside (z = 14, 15)
+            q0[b] = q1[b] = q2[b] = 0.0f;
+            if (b * TT < n) {                                                   // (uniform)
+                const uint4 r = raw[b];
+                const bool live = b * TT + t < n;
+                const unsigned in8 = live ? (r.x & 255u) : 0u;
+                clamped |= live && ((r.x >> 8) & 7u) != 7u;
+                // a corner set that is empty on the lower side of an axis: the lower corner lies one voxel before the tile
+                const bool m0 = (in8 & 0x0fu) == 0u, m1 = (in8 & 0x33u) == 0u, m2 = (in8 & 0x55u) == 0u;
+                const int v000 = (int)((r.x >> 11) & 1023u) - META_VOFF;
+                const int vv = v000 + (m0 ? 32 : 0) + (m1 ? 8 : 0) + (m2 ? 1 : 0);
+                const unsigned a0p = m0 ? 0u : ((unsigned)(vv >> 5) & 3u) + 1u, a1p = m1 ? 0u : ((unsigned)(vv >> 3) & 3u) + 1u,
+                               a2p = m2 ? 0u : ((unsigned)vv & 7u) + 1u;
+                const unsigned f = (unsigned)meta_frame(r) & 63u;
+                if (live) meta[b] = a0p | (a1p << 3) | (a2p << 6) | (meta_label(r) << 10) | (f << 18);
+                q0[b] = __uint_as_float(r.y & 0x3fffffffu); q1[b] = __uint_as_float(r.z & 0x3fffffffu); q2[b] = __uint_as_float(r.w & 0x3fffffffu);
+                // which of these frames touch which voxel (a corner outside the tile ORs into a spare word of its lane:
+                // lanes that share an address are served one by one)
+                const unsigned bit = 1u << (f & 31u);
+                const int hb = (int)(f >> 5) * 256;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int vc = v000 + ((c & 4) ? 32 : 0) + ((c & 2) ? 8 : 0) + (c & 1);
+                    atomicOr(&vm[(in8 >> c) & 1u ? hb + (vc & 127) : 512 + lane], bit);
+                }
+            }
+        }
+        team_sync<TEAM>();
+        // ---- scan: cell bases per slab (the 16 lanes of a slab scan their 32 voxels)
+        if (TEAM == 1 || t < 64) {
+            const unsigned mA0 = vm[nv0], mA1 = vm[nv0 + 1], mB0 = vm[256 + nv0], mB1 = vm[256 + nv0 + 1];
+            const int nl0 = __popc(mA0), nl1 = __popc(mA1), c0n = nl0 + __popc(mB0), c1n = nl1 + __popc(mB1);
+            int inc = c0n + c1n;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const int y = __shfl_up(inc, o, 16); if ((lane & 15) >= o) inc += y; }
+            const int ex = inc - (c0n + c1n);
+            vm[128 + nv0] = (unsigned)ex; vm[384 + nv0] = (unsigned)(ex + nl0);
+            vm[128 + nv0 + 1] = (unsigned)(ex + c0n); vm[384 + nv0 + 1] = (unsigned)(ex + c0n + nl1);
+            if ((lane & 15) == 15) misc[lane >> 4] = inc;
+        }
+        if (clamped) misc[4] = 1;
+        team_sync<TEAM>();
+        const int most = max(max(misc[0], misc[1]), max(misc[2], misc[3]));
+        const bool refuse = __builtin_amdgcn_readfirstlane(most > CW || misc[4] != 0);       // (uniform)
+        // the next item has landed by now: one word of each of its records is requested here (nothing waits for them), so
+        // that the loads at the end of this tile find the lines in L2
+        item_n.y = __builtin_amdgcn_readfirstlane(item_n.y); item_n.z = __builtin_amdgcn_readfirstlane(item_n.z);
+        unsigned touch = 0u;
+#pragma unroll
+        for (int b = 0; b < RPL; ++b)
+            if (b * TT < item_n.z) touch |= reinterpret_cast<const unsigned *>(P.rec + item_n.y + min(b * TT + t, item_n.z - 1))[0];
+
+        if (refuse) {
+            if (t == 0) {
+                const int pos = atomicAdd(&P.ticket[1 + TILE_CLASSES - 1], 1);
+                P.active_rw[(TILE_CLASSES - 1) * P.n_tiles + pos] = tile;
+                atomicAdd(&P.ticket[WAVE_REFUSED], 1);
+            }
+        } else {
+            const char *tile_base = reinterpret_cast<const char *>(P.map + ((size_t)o0 * P.size1 + o1) * ((size_t)P.size2 * C) + (size_t)o2 * C);
+            // rows of the tile that lie outside the map (a map whose extents are no multiples of four): bit 8 s + i
+            // clear; one word per thread covers four sweeps of up to eight float4s
+            unsigned rows_in = 0xffffffffu;
+            if (o0 + 4 > P.size0 || o1 + 4 > P.size1) {                        // (uniform, rare)
+                rows_in = 0u;
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < F4S; ++i) {
+                        const unsigned row = (pk[i] >> 8) & 3u;
+                        if (o0 + (s >> 1) + 2 * (int)(row >> 1) < P.size0 && o1 + (s & 1) + 2 * (int)(row & 1u) < P.size1) rows_in |= 1u << (8 * s + i);
+                    }
+            }
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                // (loop-invariant uniform conditions - which record slots and float4 slots are in use - would make the compiler
+                // clone the loop body for their combinations, 55 k instructions instead of 5 k: hidden from it)
+                int n = n_tile, C = P.C;
+                unsigned n4 = 8u * (unsigned)C;
+                asm volatile("" : "+s"(n), "+s"(n4), "+s"(C));
+                const int p0 = s >> 1, p1 = s & 1;
+                const int used = __builtin_amdgcn_readfirstlane(misc[s]);      // cells of this slab
+                const unsigned slab_off = ((unsigned)p0 * (unsigned)P.size1 + (unsigned)p1) * rsb;
+                const unsigned ok_s = rows_in >> (8 * s);
+                // ---- the slab's rows, requested now, combined at the end of the sweep
+                v4f oldv[F4S];
+#pragma unroll
+                for (int i = 0; i < F4S; ++i) {
+                    oldv[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                    if ((unsigned)(i * TT) < n4) {                              // (uniform)
+                        unsigned pki = pk[i], ofi = offs[i];
+                        asm volatile("" : "+v"(pki), "+v"(ofi));                // (nothing of them is kept across the sweeps)
+                        if (((pki >> 10) & 1u) && ((ok_s >> i) & 1u)) oldv[i] = *reinterpret_cast<const v4f *>(tile_base + (size_t)(slab_off + ofi));
+                    }
+                }
+                // ---- pass 1: W, S2 of the slab's cells (two corners per record)
+                unsigned ci[RPL], dd[RPL];                                      // the pair's two cells and two delta words (16 bits each), kept for pass 3
+                float sql[RPL], sqh[RPL];                                       // ... and its squared weights
+#pragma unroll
+                for (int b = 0; b < RPL; ++b) {
+                    ci[b] = dd[b] = 0u; sql[b] = sqh[b] = 0.0f;
+                    if (b * TT < n) {                                           // (uniform)
+                        // (the empty asm hides from the compiler that a record's fields are the same in every sweep: it would
+                        // work all of them out before the loop and hold ~20 registers per record across it)
+                        unsigned m = meta[b];
+                        float r0 = q0[b], r1 = q1[b], r2 = q2[b];
+                        asm volatile("" : "+v"(m), "+v"(r0), "+v"(r1), "+v"(r2));
+                        const int a0 = (int)(m & 7u) - 1, a1 = (int)((m >> 3) & 7u) - 1, a2 = (int)((m >> 6) & 15u) - 1;
+                        const int ca = (a0 ^ p0) & 1, cb = (a1 ^ p1) & 1;
+                        const int c0 = a0 + ca, c1 = a1 + cb;
+                        const bool in01 = (unsigned)c0 < 4u && (unsigned)c1 < 4u;
+                        const bool inl = in01 && (unsigned)a2 < 8u, inh = in01 && (unsigned)(a2 + 1) < 8u;
+                        const int vl = (c0 * 32 + c1 * 8 + a2) & 127, vh = (c0 * 32 + c1 * 8 + a2 + 1) & 127;
+                        const unsigned f = (m >> 18) & 63u, below = (1u << (f & 31u)) - 1u;
+                        const unsigned *mw = vm + (f >> 5) * 256u;
+                        const unsigned ml = mw[vl], bl = mw[128 + vl], mh = mw[vh], bh = mw[128 + vh];
+                        int cl = (int)bl + __popc(ml & below), ch = (int)bh + __popc(mh & below);
+                        cl = inl ? cl : CW + lane; ch = inh ? ch : CW + lane;   // outside: a spare cell takes it
+                        float wl, wh;
+                        pair_weights(r0, r1, r2, ca, cb, wl, wh);
+                        const float wl2 = wl * wl, wh2 = wh * wh;
+                        atomicAdd(&Wc[cl], to_fixed(wl, fx_c));
+                        atomicAdd(&Sc[cl], to_fixed(wl2, fx_c));
+                        atomicAdd(&Wc[ch], to_fixed(wh, fx_c));
+                        atomicAdd(&Sc[ch], to_fixed(wh2, fx_c));
+                        // delta words of the pair (pass 3): [32][C] at (slab voxel, class id), a spare word when outside / class id invalid
+                        const unsigned x = (m >> 10) & 255u;
+                        const bool xok = KIND == 0 || x < (unsigned)C;
+                        const int svb = ((c0 >> 1) * 2 + (c1 >> 1)) * 8;
+                        const unsigned dl = inl && xok ? (unsigned)(svb + a2) * C + (KIND == 0 ? 0u : x) : 32u * C + (lane & 31);
+                        const unsigned dh = inh && xok ? (unsigned)(svb + a2 + 1) * C + (KIND == 0 ? 0u : x) : 32u * C + (lane & 31);
+                        ci[b] = (unsigned)cl | ((unsigned)ch << 16);
+                        dd[b] = dl | (dh << 16);
+                        sql[b] = wl2; sqh[b] = wh2;
+                    }
+                    if (b & 1) __builtin_amdgcn_sched_barrier(0);               // two records at a time: the unrolled loop would keep all eight in flight (registers)
+                }
+                team_sync<TEAM>();
+                // ---- pass 2a: per cell g = iw / W, a = 1 - iw S2 / W
+                for (int i = t; i < used; i += TT) {
+                    const float rW = __builtin_amdgcn_rcpf((float)Wc[i] * fx_inv);
+                    float2 ga; ga.x = iw * rW; ga.y = 1.0f - iw * (((float)Sc[i] * fx_inv) * rW);
+                    *reinterpret_cast<float2 *>(Wc + i) = ga;
+                    Sc[i] = 0ull;
+                }
+                team_sync<TEAM>();
+                // ---- pass 2b: per voxel, from the last frame to the first: t_f = g_f prod_{f' > f} a_f'
+                if (t < 32) {
+                    const int v = (p0 + 2 * ((t >> 4) & 1)) * 32 + (p1 + 2 * ((t >> 3) & 1)) * 8 + (t & 7);
+                    const int cs = (int)vm[128 + v], cnt = __popc(vm[v]) + __popc(vm[256 + v]);
+                    float run = 1.0f;
+                    for (int j = cs + cnt - 1; j >= cs; --j) {
+                        const float2 ga = *reinterpret_cast<const float2 *>(Wc + j);
+                        reinterpret_cast<float *>(Wc + j)[0] = ga.x * run;
+                        run *= ga.y;
+                    }
+                    atot[t] = run;
+                }
+                team_sync<TEAM>();
+                // ---- pass 3: D += t_f w^2 (the class-id / ones feature is 1)
+#pragma unroll
+                for (int b = 0; b < RPL; ++b) {
+                    if (b * TT < n) {                                           // (uniform)
+                        const float tl = klow(Wc, (int)(ci[b] & 0xffffu)), th = klow(Wc, (int)(ci[b] >> 16));
+                        const float terml = sql[b] * tl, termh = sqh[b] * th;
+                        unsigned ql = (unsigned)(terml * du_scale), qh = (unsigned)(termh * du_scale);
+                        if (ql == 0u && terml > 0.0f) ql = 1u;                  // "non-zero" survives
+                        if (qh == 0u && termh > 0.0f) qh = 1u;
+                        atomicAdd(&D[dd[b] & 0xffffu], ql);
+                        atomicAdd(&D[dd[b] >> 16], qh);
+                    }
+                    if (b & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                team_sync<TEAM>();
+                for (int i = t; i < used; i += TT) Wc[i] = 0ull;                // the slab's cells
+                // ---- final pass of the slab: old * prod a + D, two floats per instruction
+#pragma unroll
+                for (int i = 0; i < F4S; ++i) {
+                    if ((unsigned)(i * TT) < n4) {                              // (uniform)
+                        unsigned pki = pk[i], ofi = offs[i];
+                        asm volatile("" : "+v"(pki), "+v"(ofi));
+                        if ((pki >> 10) & 1u) {
+                            const unsigned j = t + (unsigned)TT * i;
+                            const uint4 dq = *reinterpret_cast<const uint4 *>(D + 4u * j);
+                            *reinterpret_cast<uint4 *>(D + 4u * j) = make_uint4(0u, 0u, 0u, 0u);
+                            const unsigned sv0 = pki & 31u, cross = (pki >> 5) & 7u;
+                            float ak[4];
+                            if (C >= 4) {                                       // (uniform) a float4 spans two voxels at most
+                                const float a0 = atot[sv0], a1 = atot[(sv0 + 1u) & 31u];
+                                ak[0] = a0; ak[1] = cross > 1u ? a0 : a1; ak[2] = cross > 2u ? a0 : a1; ak[3] = cross > 3u ? a0 : a1;
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) ak[k] = atot[div_magic(4u * j + k, P.magicC) & 31u];
+                            }
+                            const bool changed = (dq.x | dq.y | dq.z | dq.w) != 0u || ak[0] != 1.0f || ak[3] != 1.0f || (C < 4 && (ak[1] != 1.0f || ak[2] != 1.0f));
+                            if (((ok_s >> i) & 1u) && changed) {
+                                const v2f d01 = (v2f){(float)dq.x, (float)dq.y} * (v2f){du_inv, du_inv};
+                                const v2f d23 = (v2f){(float)dq.z, (float)dq.w} * (v2f){du_inv, du_inv};
+                                const v2f o01 = __builtin_elementwise_fma((v2f){oldv[i][0], oldv[i][1]}, (v2f){ak[0], ak[1]}, d01);
+                                const v2f o23 = __builtin_elementwise_fma((v2f){oldv[i][2], oldv[i][3]}, (v2f){ak[2], ak[3]}, d23);
+                                *reinterpret_cast<v4f *>(const_cast<char *>(tile_base) + (size_t)(slab_off + ofi)) = (v4f){o01[0], o01[1], o23[0], o23[1]};
+                            }
+                        }
+                    }
+                    if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                team_sync<TEAM>();
+            }
+        }
+        // the masks of this tile, the refuse flag
+        if (TEAM == 1 || t < 64) { vm[nv0] = 0u; vm[nv0 + 1] = 0u; vm[256 + nv0] = 0u; vm[256 + nv0 + 1] = 0u; }
+        if (t == 0) misc[4] = 0;
+        team_sync<TEAM>();
+        item = item_n;
+        asm volatile("" :: "v"(touch));                                         // (keeps the touching loads)
+        load_records(item.y, item.z, raw);
+    }
+}
+
+// ----------------------------------------------------------------------------
 // single-group calls with class-id / ones features: one pass, integer sums
 // ----------------------------------------------------------------------------
 // With one group (a frame, or a merged batch) the update of a voxel is
@@ -2702,7 +3094,7 @@ static size_t tile_lds_bytes(int C, int sv, int gc, int G, bool lean)
 }
 
 struct Layout {
-    size_t cursor, block_sums, ticket, slot_count, slot_ws, slot_u, slot_bits, active, items, rec, aux, pts, total;
+    size_t cursor, block_sums, ticket, slot_count, slot_ws, slot_u, slot_bits, active, light, items, rec, aux, pts, total;
     int n_keys, n_scan_blocks;
     int split_slots, split_items;      // 0: no split tiles (sequential groups, or MF_SPLIT=0)
     long long cap;
@@ -2760,6 +3152,7 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
         L.slot_count = L.slot_ws = L.slot_u = L.slot_bits = off;
     }
     L.active = off; off = align_up(off + (size_t)(n_keys / G) * TILE_CLASSES * 4, 256);
+    L.light = off; off = align_up(off + (size_t)(n_keys / G) * 2 * 16, 256);      // work items of fuse_wave_kernel (two lists)
     L.items = off; off = align_up(off + (size_t)L.split_items * 8, 256);
     L.rec = off; off = align_up(off + (size_t)cap * 16, 256);
     L.aux = off; off = align_up(off + (size_t)cap * 4, 256);
@@ -2986,6 +3379,14 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (blocks_cap > 0 && blocks_cells > blocks_cap) blocks_cells = blocks_cap;
     if (blocks_cells > P.n_tiles) blocks_cells = P.n_tiles;
 
+    // the light and medium tiles of such a batch go to fuse_wave_kernel, one wave / one workgroup each (MF_WAVE_MAX /
+    // MF_TEAM_MAX: records up to which a tile counts as light / medium, 0 keeps the kernel out; dev / tests)
+    static const int wave_max = env_int("MF_WAVE_MAX", 0, 64 * WAVE_RPL, 0);
+    static const int team_max = env_int("MF_TEAM_MAX", 0, 256 * WAVE_RPL, 0);
+    const size_t wlds1 = wave_lds_bytes(P.C, 1) * (WAVE_NT / 64), wlds4 = wave_lds_bytes(P.C, 4);
+    const bool wave_ok = use_cells && P.G <= 64 && P.C <= 64;
+    const bool use_wave = wave_ok && wave_max > 0 && 2 * wlds1 <= (size_t)dev.lds_per_cu;
+    const bool use_team = wave_ok && team_max > 0 && 3 * wlds4 <= (size_t)dev.lds_per_cu;
     const int list_dense_tv = (use_dense || use_cells ? 1 << sv : 0) | (use_dense ? 1 << 20 : 0) | (use_cells ? 1 << 21 : 0) |
                               (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0) |
                               (P.meta ? 1 << 24 : 0);
@@ -2998,6 +3399,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     LM.min_mean = P.feat_kind == MF_FEAT_ONES || mc ? 0 : single_min_mean;
     LM.first_ticket = 4 * blocks; LM.dense_tv = list_dense_tv; LM.first_ticket_dense = 4 * blocks_dense; LM.first_ticket_cells = blocks_cells;
     LM.abort = follower ? mc->abort : P.ticket + ABORT_SLOT;
+    LM.light_max = use_wave ? wave_max : 0; LM.medium_max = use_team ? team_max : 0; LM.light = (int4 *)(ws + L.light);
     if (mc && mc->role == 2) { *mc->plan = LM; return MF_OK; }
     if (follower) {
         // the first map's kernels have zeroed this map's counters and split scratch, found its feature range and
@@ -3026,6 +3428,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     {
         ListParams LP;
         LP.cursor = P.cursor; LP.n_tiles = P.n_tiles; LP.G = P.G; LP.split_part = split_part();
+        LP.nt1 = P.nt1; LP.nt2 = P.nt2; LP.s0 = P.s0; LP.s1 = P.s1; LP.s2 = P.s2;
         LP.nonempty = P.ticket + SPLIT_NONEMPTY;
         LP.map[0] = LM;
         const int n_lists = mc && mc->role == 0 ? mc->n_lists : 0;
@@ -3078,6 +3481,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     T.ctr = P.ticket;
     T.cells_cap = cells_cap;
     T.meta = P.meta;
+    T.active_rw = nullptr; T.light = nullptr; T.wave_lds = 0;
     // with ones features every tile of a single-group call goes to the single-pass kernel (tile_list_kernel,
     // min_mean = 0): nothing is listed for the tile kernel, whose launch is skipped
     if (!(single && LM.min_mean == 0)) {
@@ -3112,6 +3516,37 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         S.ctr = P.ticket + TICKET_DENSE;
         hipLaunchKernelGGL(dk, dim3(blocks_dense), dim3(dnt), dlds, st, S);   // returns at once unless tile_list_kernel chose it
         MF_LAUNCH_CHECK("fuse_dense_kernel");
+    }
+    // before fuse_cells_kernel: a tile they refuse is appended to that kernel's list
+    for (int team = 4; team >= 1; team -= 3) {          // the four-wave teams first: their tiles are the longer ones
+        if (team == 4 ? !use_team : !use_wave) continue;
+        const int per_team = 64 * team, f4s = (8 * P.C + per_team - 1) / per_team;       // float4s per thread and slab
+        void (*wk)(TileParams);
+        if (team == 1) {
+            if (kind == 0) wk = fuse_wave_kernel<0, 1, WAVE_RPL, 1>;
+            else wk = f4s <= 1 ? fuse_wave_kernel<1, 1, WAVE_RPL, 1> : f4s <= 2 ? fuse_wave_kernel<1, 1, WAVE_RPL, 2>
+                    : f4s <= 4 ? fuse_wave_kernel<1, 1, WAVE_RPL, 4> : fuse_wave_kernel<1, 1, WAVE_RPL, 8>;
+        } else {
+            if (kind == 0) wk = fuse_wave_kernel<0, 4, WAVE_RPL, 1>;
+            else wk = f4s <= 1 ? fuse_wave_kernel<1, 4, WAVE_RPL, 1> : fuse_wave_kernel<1, 4, WAVE_RPL, 2>;
+        }
+        const size_t wl = team == 1 ? wlds1 : wlds4;
+        {
+            static std::mutex mu5;
+            static std::unordered_map<const void *, size_t> granted5;
+            std::lock_guard<std::mutex> lock(mu5);
+            size_t &have = granted5[(const void *)wk];
+            if (have < wl) {
+                MF_HIP_CHECK(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
+                have = wl;
+            }
+        }
+        TileParams S = T;
+        S.active_rw = P.active; S.light = (const int4 *)(ws + L.light); S.wave_lds = (int)wave_lds_bytes(P.C, 1);
+        int wblocks = dev.cus * (team == 1 ? 2 : 3);
+        if (blocks_cap > 0 && wblocks > blocks_cap) wblocks = blocks_cap;
+        hipLaunchKernelGGL(wk, dim3(wblocks), dim3(WAVE_NT), wl, st, S);   // returns at once unless tile_list_kernel chose the cells path
+        MF_LAUNCH_CHECK("fuse_wave_kernel");
     }
     if (use_cells) {
         const int f4 = (int)((((size_t)P.C << 3) / 4 + 63) / 64);          // float4s per lane and tile row
