@@ -509,6 +509,51 @@ def extra_workloads(lay_kw, dev, frames_a, poses_a, depth_a, label_a):
 
 
 # ----------------------------------------------------------------------------------------------
+def episode_split(prepared, layers, batch):
+    """Where one episode's time goes (ms): the two maps' fusion, then predict_scene_differences cut into the whole-map
+    reduction (amax_z), the contour step on the host, the per-box moments, the pairwise cost and the assignment.
+    Every piece is bracketed by torch.cuda.synchronize(), so the sum is an upper bound of the pipelined time."""
+    import mass_amd.utils.experimentation as ex
+    import mass_amd.nn.applications.semantic_projection_layer as spl
+    from mass_amd.episodes import run_episode
+    acc = {}
+
+    def timed(name, fn):
+        def wrapper(*a, **k):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = fn(*a, **k)
+            torch.cuda.synchronize()
+            acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+            return out
+        return wrapper
+    saved = (spl.amax_z, spl.contour_boxes, spl.lib.mf_roi_moments, ex.pairwise_distance, ex.linear_sum_assignment,
+             layers[0].__class__.update_batch, ex.predict_scene_differences)
+    try:
+        spl.amax_z = timed("amax_z", saved[0])
+        spl.contour_boxes = timed("contours_host", saved[1])
+        ex.pairwise_distance = timed("pairwise", saved[3])
+        ex.linear_sum_assignment = timed("assignment_host", saved[4])
+        layers[0].__class__.update_batch = timed("fuse_two_maps", saved[5])
+        import mass_amd.episodes as epi
+        psd = timed("predict_scene_differences_total", saved[6])
+        ex.predict_scene_differences = psd
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        run_episode(prepared[0], layers, batch=batch)
+        torch.cuda.synchronize()
+        acc["episode_total"] = (time.perf_counter() - t) * 1e3
+    finally:
+        spl.amax_z, spl.contour_boxes = saved[0], saved[1]
+        ex.pairwise_distance, ex.linear_sum_assignment = saved[3], saved[4]
+        layers[0].__class__.update_batch = saved[5]
+        ex.predict_scene_differences = saved[6]
+    if "predict_scene_differences_total" in acc:
+        acc["find_other (roi moments, transfers, python)"] = acc["predict_scene_differences_total"] - sum(
+            acc.get(k, 0.0) for k in ("amax_z", "contours_host", "pairwise", "assignment_host"))
+    return {k: round(v, 3) for k, v in acc.items()}
+
+
 def run_episode_rank(args, rank, world, dev, D):
     """BASELINE configs[4]: --episodes synthetic episodes sharded over the ranks like the
     reference shards tasks (agent.py:154-155: episode e on rank e mod world), each a walkthrough and an unshuffle
@@ -541,6 +586,7 @@ def run_episode_rank(args, rank, world, dev, D):
     barrier()
     wall = time.perf_counter() - t0
     wall_max = D.max_over_ranks(wall)
+    split = episode_split(prepared, layers, args.batch) if rank == 0 and prepared else None     # untimed, after the timed region
     for k in ("episodes", "frames", "moved_found", "n_matches", "shift_m", "occupied_voxels", "map_abs_sum"):
         counters.setdefault(k, 0.0)                      # a rank without episodes still takes part in the all-reduce
     metrics = D.reduce_metrics(counters)                 # the run's one data collective
@@ -556,7 +602,12 @@ def run_episode_rank(args, rank, world, dev, D):
                                    f"{args.batch}) + predict_scene_differences, episodes sharded over the ranks, one metrics "
                                    f"all-reduce", "episodes": args.episodes, "frames_per_episode": 2 * args.episode_frames},
             "metrics_allreduce": metrics,
-            "note": "strong scaling: the episode count is fixed, ranks share it; includes find() + matching per episode"}),
+            "per_episode_ms": split,
+            "host": {"cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(),
+                     "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")},
+            "note": "strong scaling: the episode count is fixed, ranks share it; includes find() + matching per episode; "
+                    "per_episode_ms: one extra untimed round of rank 0's first episode with a device synchronisation around "
+                    "every piece (so the pieces do not overlap as they do in the timed rounds)"}),
             flush=True)
     if world > 1:
         D.barrier()

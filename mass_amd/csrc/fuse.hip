@@ -28,8 +28,9 @@
 //                  only, three 256-thread workgroups per CU (see there);
 //        fuse_dense_kernel   the same feature kinds, real scenes: everything accumulated as integers on
 //                  4 x 4 x 8 tiles, suffix form of the unrolled blend (see there);
-//                  (both read tile-local "meta" records, make_meta_record; tile_list_kernel picks one of
-//                  the two from the call's own point density: no state is kept between calls)
+//                  (both read tile-local CONTRIBUTIONS, make_contribution: scatter_kernel expands a point into
+//                  one 8-byte entry per corner of its footprint, in the bucket of the corner's tile; tile_list_kernel
+//                  picks one of the two from the call's own point density: no state is kept between calls)
 //        fuse_tiles_kernel   dense fp32 features, blend weights outside [0, 1], any tile shape: persistent
 //                  workgroups walk the tile list (ticket counter; the next tile's ticket, id,
 //                  offsets and first records are fetched one tile ahead).  The tile's old map
@@ -54,6 +55,7 @@
 // MF_DENSE_GC / MF_DENSE_NT / MF_CELLS_PER_CU size them, MF_BLOCKS caps the workgroups,
 // MF_STAMPS=1 prints the share of each phase of the tile kernel (dev builds of bench runs).
 #include <cstdlib>
+#include <type_traits>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -91,7 +93,7 @@ struct FuseParams {
     int nt0, nt1, nt2, n_tiles, n_keys;
     int gc;                    // frames per chunk in the tile kernel
     int vec4;                  // final pass may use 16-byte accesses
-    int meta;                  // records in the tile-local "meta" format (all-integer tile kernels), no aux words
+    int meta;                  // entries in the tile-local format: one contribution per corner (all-integer tile kernels), no aux words
     unsigned magicC;           // ceil(2^32 / C) (0 when C == 1)
     // workspace
     int *cursor;               // [n_keys + 1]
@@ -128,7 +130,7 @@ struct TileParams {
     int nt1, nt2, n_tiles;
     unsigned magicC;
     int gc, vec4, fx_shift;
-    int meta;                  // records are in the meta format (see make_meta_record)
+    int meta;                  // the entries are tile-local contributions (see make_contribution)
     int cells_cap;             // fuse_cells_kernel: (voxel, frame) cells that fit its LDS
     const int *cursor;
     int *ticket;
@@ -136,10 +138,7 @@ struct TileParams {
     const int *active;
     const uint4 *rec;
     const uint32_t *aux;
-    // fuse_wave_kernel (light tiles, one wave each)
-    int *active_rw;            // the work list again, writable: a tile it cannot take is appended to the last load class
-    const int4 *light;         // its work items (tile_list_kernel): {tile, first record, records, origin 10 + 10 + 10 bits}
-    int wave_lds;              // bytes of LDS per wave
+    const int4 *light;         // fuse_cells_kernel's work items [CELL_CLASSES][n_tiles] (tile_list_kernel): {tile, first entry, entries, origin 10 + 10 + 10 bits}
 };
 
 struct Point {
@@ -248,6 +247,7 @@ __device__ __forceinline__ Pix patch_pixel(const FuseParams &P)
 struct TileKeys {
     uint32_t key[8];
     unsigned mask;
+    unsigned straddle;         // bit 2 / 1 / 0: the footprint's two corners of axis 0 / 1 / 2 lie in different tiles
     AxisFoot a0, a1, a2;
     int t0[2], t1[2], t2[2];
 };
@@ -258,6 +258,7 @@ __device__ __forceinline__ void point_keys8(const FuseParams &P, const Point &pt
     K.t1[0] = K.a1.lo >> P.s1; K.t1[1] = K.a1.hi >> P.s1;
     K.t2[0] = K.a2.lo >> P.s2; K.t2[1] = K.a2.hi >> P.s2;
     const bool m0 = K.t0[0] != K.t0[1], m1 = K.t1[0] != K.t1[1], m2 = K.t2[0] != K.t2[1];
+    K.straddle = (m0 ? 4u : 0u) | (m1 ? 2u : 0u) | (m2 ? 1u : 0u);
     K.mask = 0u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -294,10 +295,12 @@ constexpr uint32_t EMPTY = 0xffffffffu;
 #endif
 constexpr int HS_FILL = HS_FILL_DEF, HS_PROBES = HS_PROBES_DEF;
 
-__device__ __forceinline__ int hash_insert(uint32_t *hkey, int *hcnt, int *hfill, uint32_t key, int &rank)
+// `open`: the table still takes new keys (hash_open, read ONCE per point: eight LDS round trips per thread otherwise)
+__device__ __forceinline__ bool hash_open(const int *hfill) { return *(volatile const int *)hfill < HS_FILL; }
+
+__device__ __forceinline__ int hash_insert(uint32_t *hkey, int *hcnt, int *hfill, uint32_t key, int &rank, bool open, int inc = 1)
 {
     uint32_t h = (key * 2654435761u) >> (32 - HS_BITS);
-    const bool open = *(volatile int *)hfill < HS_FILL;
 #if HS_CLOSED_SKIP_DEF
     if (!open) return -1;          // a closed table is not even searched: the block's keys are (nearly) all different
 #endif
@@ -308,7 +311,7 @@ __device__ __forceinline__ int hash_insert(uint32_t *hkey, int *hcnt, int *hfill
             cur = atomicCAS(&hkey[h], EMPTY, key);
             if (cur == EMPTY) { atomicAdd(hfill, 1); cur = key; }
         }
-        if (cur == key) { rank = atomicAdd(&hcnt[h], 1); return (int)h; }
+        if (cur == key) { rank = atomicAdd(&hcnt[h], inc); return (int)h; }
         h = (h + 1) & (HS - 1);
     }
     return -1;
@@ -328,86 +331,19 @@ __device__ __forceinline__ uint4 make_record(const Point &pt)
 }
 
 // ----------------------------------------------------------------------------
-// tile-local records ("meta" format) of the all-integer tile kernels
+// tile-local entries ("meta" format) of the all-integer tile kernels: CONTRIBUTIONS
 // ----------------------------------------------------------------------------
-// A record is written per (point, tile) pair anyway, so for the calls that go to fuse_dense_kernel /
-// fuse_cells_kernel (sequential or merged frames of class ids / ones, front end 0) scatter_kernel stores what the
-// tile kernels would otherwise derive again in every pass, in the same 16 bytes and with no separate class-id word:
-//   x  bits  0..7   corner c = 4 ca + 2 cb + cd lies inside the tile (ca / cb / cd pick the upper corner of axis 0 / 1 / 2)
-//      bits  8..10  d0 d1 d2: upper minus lower voxel index per axis (0 where the footprint is clamped at the map border)
-//      bits 11..20  tile-local id of the all-lower corner + META_VOFF (it may lie one voxel before the tile)
-//      bits 21..28  class id (255 = outside [0, C), counts as an all-zero feature row), bits 29..30 frame bits 6..7
-//   y, z, w  the three ratios (in [0, 1]: sign and top exponent bit clear); their two top bits carry frame bits 0..5.
-constexpr int META_VOFF = 128;
-
-struct AxisLocal { int l, d; bool in_lo, in_hi; };
-__device__ __forceinline__ AxisLocal axis_local(const AxisFoot &a, int origin, int shift)
+// For the calls that go to fuse_dense_kernel / fuse_cells_kernel (sequential or merged frames of class ids / ones,
+// front end 0) scatter_kernel expands a point where its geometry is at hand anyway: one 8-byte contribution per
+// corner of the 2 x 2 x 2 footprint, written to the bucket of the tile the corner lies in (rounds 2-3 wrote one
+// 16-byte record per (point, tile) and the tile kernels worked the eight corners out again in each of their passes):
+//   x  bits  0..6   voxel inside the tile (4 x 4 x 8: l0 * 32 + l1 * 8 + l2)
+//      bits  7..14  class id (255 = outside [0, C), counts as an all-zero feature row)
+//      bits 15..22  frame (sequential group)
+//   y  the corner weight 1e-9 + (w0 * w1) * w2 (projection.py:319-323), fp32
+__device__ __forceinline__ uint2 make_contribution(int v, uint32_t label, int frame, float w)
 {
-    AxisLocal x;
-    x.l = a.lo - origin;
-    x.d = a.hi - a.lo;
-    x.in_lo = ((unsigned)x.l >> shift) == 0u;
-    x.in_hi = ((unsigned)(a.hi - origin) >> shift) == 0u;
-    return x;
-}
-
-__device__ __forceinline__ uint4 make_meta_record(const Point &pt, const AxisFoot &a0, const AxisFoot &a1, const AxisFoot &a2,
-                                                  int o0, int o1, int o2, int s0, int s1, int s2, uint32_t label)
-{
-    const AxisLocal x0 = axis_local(a0, o0, s0), x1 = axis_local(a1, o1, s1), x2 = axis_local(a2, o2, s2);
-    const uint32_t in8 = ((x0.in_lo ? 0x0fu : 0u) | (x0.in_hi ? 0xf0u : 0u)) & ((x1.in_lo ? 0x33u : 0u) | (x1.in_hi ? 0xccu : 0u)) &
-                         ((x2.in_lo ? 0x55u : 0u) | (x2.in_hi ? 0xaau : 0u));
-    const int v000 = x0.l * (1 << (s1 + s2)) + x1.l * (1 << s2) + x2.l;
-    const uint32_t g = (uint32_t)pt.group;
-    uint4 r;
-    r.x = in8 | ((uint32_t)x0.d << 8) | ((uint32_t)x1.d << 9) | ((uint32_t)x2.d << 10) | ((uint32_t)(v000 + META_VOFF) << 11) |
-          ((label > 255u ? 255u : label) << 21) | (((g >> 6) & 3u) << 29);
-    r.y = __float_as_uint(pt.r0) | ((g & 3u) << 30);
-    r.z = __float_as_uint(pt.r1) | (((g >> 2) & 3u) << 30);
-    r.w = __float_as_uint(pt.r2) | (((g >> 4) & 3u) << 30);
-    return r;
-}
-
-__device__ __forceinline__ int meta_frame(const uint4 &r)
-{
-    return (int)((r.y >> 30) | ((r.z >> 30) << 2) | ((r.w >> 30) << 4) | (((r.x >> 29) & 3u) << 6));
-}
-__device__ __forceinline__ uint32_t meta_label(const uint4 &r) { return (r.x >> 21) & 255u; }
-
-// What a pass needs of a meta record: tile-local ids and weights of the eight corners (static register picks once
-// the corner loop is unrolled), the inside mask.
-template <int S1, int S2>
-struct MetaCorners {
-    int v[8];
-    float w[8];
-    uint32_t in8;
-    __device__ __forceinline__ explicit MetaCorners(const uint4 &r)
-    {
-        in8 = r.x & 255u;
-        const int v000 = (int)((r.x >> 11) & 1023u) - META_VOFF;
-        const int e0 = (int)((r.x >> 8) & 1u) << (S1 + S2), e1 = (int)((r.x >> 9) & 1u) << S2, e2 = (int)((r.x >> 10) & 1u);
-        v[0] = v000; v[1] = v000 + e2; v[2] = v000 + e1; v[3] = v[2] + e2;
-        v[4] = v000 + e0; v[5] = v[4] + e2; v[6] = v[4] + e1; v[7] = v[6] + e2;
-        const float r0 = __uint_as_float(r.y & 0x3fffffffu), r1 = __uint_as_float(r.z & 0x3fffffffu), r2 = __uint_as_float(r.w & 0x3fffffffu);
-        // per axis (projection.py:280-316): r < 0.5: (0.5 - r, r + 0.5), else (1.5 - r, r - 0.5)
-        const float l0 = (r0 < 0.5f ? 0.5f : 1.5f) - r0, h0 = r0 + (r0 < 0.5f ? 0.5f : -0.5f);
-        const float l1 = (r1 < 0.5f ? 0.5f : 1.5f) - r1, h1 = r1 + (r1 < 0.5f ? 0.5f : -0.5f);
-        const float l2 = (r2 < 0.5f ? 0.5f : 1.5f) - r2, h2 = r2 + (r2 < 0.5f ? 0.5f : -0.5f);
-        // (w0 * w1) * w2 + 1e-9, the reference's product order (projection.py:319-323)
-        const float w00 = l0 * l1, w01 = l0 * h1, w10 = h0 * l1, w11 = h0 * h1;
-        w[0] = 1e-9f + w00 * l2; w[1] = 1e-9f + w00 * h2; w[2] = 1e-9f + w01 * l2; w[3] = 1e-9f + w01 * h2;
-        w[4] = 1e-9f + w10 * l2; w[5] = 1e-9f + w10 * h2; w[6] = 1e-9f + w11 * l2; w[7] = 1e-9f + w11 * h2;
-    }
-};
-
-// body(cc, v, w) for the corners of a meta record that lie inside the tile
-template <int S1, int S2, class F>
-__device__ __forceinline__ void meta_corners_idx(const uint4 &r, F body)
-{
-    const MetaCorners<S1, S2> m(r);
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc)
-        if (m.in8 & (1u << cc)) body(cc, m.v[cc], m.w[cc]);
+    return make_uint2((uint32_t)v | ((label > 255u ? 255u : label) << 7) | ((uint32_t)frame << 15), __float_as_uint(w));
 }
 
 template <int FRONT>
@@ -444,11 +380,16 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
         if (ok) {
             TileKeys K;
             point_keys8(P, pt, K);
+            // entries of a bucket: one record per (point, tile), or - tile-local "meta" entries - one contribution per corner
+            // inside the tile: the eight corners split evenly over the point's tiles (an axis whose two corners straddle a
+            // tile face halves the share)
+            const int inc = P.meta ? 8 >> __popc(K.straddle) : 1;
+            const bool open = hash_open(&hfill);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (K.mask & (1u << j)) {
                     int rank;
-                    if (hash_insert(hkey, hcnt, &hfill, K.key[j], rank) < 0) atomicAdd(&P.cursor[K.key[j]], 1);
+                    if (hash_insert(hkey, hcnt, &hfill, K.key[j], rank, open, inc) < 0) atomicAdd(&P.cursor[K.key[j]], inc);
                 }
         }
     }
@@ -523,9 +464,13 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
     }
     if (ok) {
         point_keys8(P, pt, K);
+    }
+    const int inc_k = ok && P.meta ? 8 >> __popc(K.straddle) : 1;
+    if (ok) {
+        const bool open = hash_open(&hfill);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (K.mask & (1u << j)) slot[j] = hash_insert(hkey, hcnt, &hfill, K.key[j], rank[j]);
+            if (K.mask & (1u << j)) slot[j] = hash_insert(hkey, hcnt, &hfill, K.key[j], rank[j], open, inc_k);
     }
     __syncthreads();
     // one returning global atomic per distinct bucket of this block; hcnt becomes the base
@@ -536,23 +481,58 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
         // positions first (the returning atomics of the buckets that are not in the table all in flight), then the stores
         int pos[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (K.mask & (1u << j)) pos[j] = slot[j] >= 0 ? hcnt[slot[j]] + rank[j] : atomicAdd(&P.cursor[K.key[j]], 1);
+        for (int j = 0; j < 8; ++j) {
+            pos[j] = 0;
+            if (K.mask & (1u << j)) pos[j] = slot[j] >= 0 ? hcnt[slot[j]] + rank[j] : atomicAdd(&P.cursor[K.key[j]], inc_k);
+        }
+        if (P.meta) {
+            // Tile-local entries for the all-integer tile kernels: one CONTRIBUTION per corner, written to the bucket of the
+            // corner's own tile (make_contribution: voxel inside the tile, class id, frame, corner weight).  Corner c = 4 ca +
+            // 2 cb + cd belongs to key position c & straddle; inside a (point, tile) share the corners are numbered by
+            // their free bits.  A footprint clamped at the map border has two corners on one voxel: both are written,
+            // like the reference scatters both (projection.py:294-298).
+            const unsigned sd = K.straddle;
+            const bool m0 = sd & 4u, m1 = sd & 2u, m2 = sd & 1u;
+            const int s2n = m2 ? 1 : 2, u1 = m1 ? 0 : s2n, u0 = m0 ? 0 : s2n * (m1 ? 1 : 2);     // (the z pair of a share is adjacent)
+            const float w00 = K.a0.wlo * K.a1.wlo, w01 = K.a0.wlo * K.a1.whi, w10 = K.a0.whi * K.a1.wlo, w11 = K.a0.whi * K.a1.whi;
+            const int x0[2] = {(K.a0.lo & ((1 << P.s0) - 1)) << (P.s1 + P.s2), (K.a0.hi & ((1 << P.s0) - 1)) << (P.s1 + P.s2)};
+            const int x1[2] = {(K.a1.lo & ((1 << P.s1) - 1)) << P.s2, (K.a1.hi & ((1 << P.s1) - 1)) << P.s2};
+            const int x2[2] = {K.a2.lo & ((1 << P.s2) - 1), K.a2.hi & ((1 << P.s2) - 1)};
+            uint2 *out = reinterpret_cast<uint2 *>(P.rec);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (K.mask & (1u << j)) {
-                if (P.meta) {      // tile-local records for the all-integer tile kernels (no separate class-id word)
-                    const int a = j >> 2, b = (j >> 1) & 1, c = j & 1;
-                    P.rec[pos[j]] = make_meta_record(pt, K.a0, K.a1, K.a2, K.t0[a] << P.s0, K.t1[b] << P.s1, K.t2[c] << P.s2,
-                                                     P.s0, P.s1, P.s2, aux);
+            for (int cab = 0; cab < 4; ++cab) {
+                const int ca = cab >> 1, cb = cab & 1;
+                // position of the share: pos[c & straddle], picked with static selects
+                const bool ja = ca && m0, jb = cb && m1;
+                const int base_lo = ja ? (jb ? pos[6] : pos[4]) : (jb ? pos[2] : pos[0]);        // corner cd = 0 (and cd = 1 when z does not straddle)
+                const int base_hi = ja ? (jb ? pos[7] : pos[5]) : (jb ? pos[3] : pos[1]);        // corner cd = 1 when z straddles
+                const int idx = ca * u0 + cb * u1;
+                // (w0 * w1) * w2 + 1e-9, the reference's product order (projection.py:319-323)
+                const float wab = ca ? (cb ? w11 : w10) : (cb ? w01 : w00);
+                const uint2 lo = make_contribution(x0[ca] | x1[cb] | x2[0], aux, pt.group, 1e-9f + wab * K.a2.wlo);
+                const uint2 hi = make_contribution(x0[ca] | x1[cb] | x2[1], aux, pt.group, 1e-9f + wab * K.a2.whi);
+                // The z pair of a share is adjacent: ONE 16-byte store unless z straddles a tile face (one time in eight).
+                // The write requests that reach the L2, not the instructions, bound this kernel: 8-byte stores of a wave's
+                // 64 lanes are 64 requests each.
+                if (!m2) {
+                    uint4 q; q.x = lo.x; q.y = lo.y; q.z = hi.x; q.w = hi.y;
+                    __builtin_memcpy(out + base_lo + idx, &q, 16);       // (8-byte aligned)
                 } else {
+                    out[base_lo + idx] = lo;
+                    out[base_hi + idx] = hi;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (K.mask & (1u << j)) {
                     P.rec[pos[j]] = r;
                     if (P.feat_kind != MF_FEAT_ONES) P.aux[pos[j]] = aux;
                     if (FRONT == 0)
                         for (int m = 0; m < P.n_extra; ++m)
                             if (P.extra[m].aux) P.extra[m].aux[pos[j]] = xaux[m];
                 }
-            }
+        }
     }
 }
 
@@ -640,11 +620,17 @@ constexpr int MODE_SLOT = ABORT_SLOT + 5;       // which tile kernel takes the c
 constexpr int HINT_SLOT = ABORT_SLOT + 6;       // [2] records listed, non-empty buckets x tile voxels / 2 (diagnostics)
 constexpr int TICKET_DENSE = ABORT_SLOT + 8;    // work counter of fuse_dense_kernel (ticket[0] is fuse_tiles_kernel's)
 constexpr int TICKET_CELLS = ABORT_SLOT + 9;    // work counter of fuse_cells_kernel
-constexpr int LIGHT_COUNT = ABORT_SLOT + 10;    // items of fuse_wave_kernel, one-wave teams (light tiles of a sparse batch)
-constexpr int MEDIUM_COUNT = ABORT_SLOT + 11;   // its items for four-wave teams (medium tiles)
-constexpr int WAVE_REFUSED = ABORT_SLOT + 12;   // tiles it handed on to fuse_cells_kernel (diagnostics)
 constexpr int ABORT_MAPS = 32;                  // [MAX_EXTRA_MAPS] abort words of the further maps of a mf_fuse_frame_maps call
 constexpr int ABSMAX_MAPS = 36;                 // [MAX_EXTRA_MAPS] their FEAT_ABSMAX words
+// fuse_cells_kernel deals its work list statically (no ticket: see there), which balances only if the tiles of a load
+// class cost about the same: its list has half-octave classes of the entry count, heaviest first
+constexpr int CELL_CLASSES = 40;                // entries >= 2^19.5 ... < 2
+constexpr int CELL_COUNT = 64;                  // ticket[CELL_COUNT + c]: tiles in fine class c (the counter block has 128 words)
+__device__ __forceinline__ int cell_class(int n)     // n >= 1
+{
+    const int l = 31 - __clz(n), key = 2 * l + (l > 0 ? (n >> (l - 1)) & 1 : 0);
+    return max(0, CELL_CLASSES - 1 - key);
+}
 constexpr int MODE_TILES = 0, MODE_DENSE = 2, MODE_CELLS = 3;
 constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
@@ -657,13 +643,13 @@ struct ListMap {
     int *ticket, *active, *items;
     int split_min, split_slots, min_mean, first_ticket, dense_tv, first_ticket_dense, first_ticket_cells;
     const int *abort;              // a class id of this map was out of range
-    int light_max, medium_max;     // tiles of a sparse batch with at most this many records go to fuse_wave_kernel, one wave / four waves per tile (0: none)
-    int4 *light;                   // its work items: [n_tiles] one-wave teams, [n_tiles] four-wave teams
+    int4 *items4;                  // [CELL_CLASSES][n_tiles] work items of fuse_cells_kernel (in place of `active` when it takes the call)
 };
 struct ListParams {
     const int *cursor;             // exclusive offsets
     int n_tiles, G, split_part;
-    int nt1, nt2, s0, s1, s2;      // tile grid (the origin of a light tile rides in its work item)
+    int nt1, nt2, s0, s1, s2;      // tile grid (the origin of a tile rides in fuse_cells_kernel's work item)
+    int meta;                      // the entries are contributions (tile-local format)
     const int *nonempty;           // buckets with entries (scan_apply_kernel)
     ListMap map[1 + MAX_EXTRA_MAPS];
 };
@@ -684,7 +670,9 @@ __global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
     // voxel and frame or more is a real scene (a batch of unrelated frames has 0.03): the all-integer
     // tile kernel takes it when the call was bucketed on its tiles (dense_tv = their voxel count, else 0).
     // (every thread works the choice out: which list a tile goes to depends on it)
-    const long long total = cursor[n_tiles * G], half = (long long)*nonempty * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
+    // (counted in points: a contribution is 2 / 9 of a point's entry in a tile, 8 corners over 1.76 tiles on average)
+    const long long total = LP.meta ? (long long)cursor[n_tiles * G] * 2 / 9 : (long long)cursor[n_tiles * G];
+    const long long half = (long long)*nonempty * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
     // bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is, bits 22 / 23: forced (dev / tests),
     // bit 24: the records are tile-local (meta format): only these two kernels read them
     const bool dense_ok = dense_tv & (1 << 20), cells_ok = dense_tv & (1 << 21);
@@ -721,26 +709,28 @@ __global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
         return;                                     // nothing is listed for the tile kernel
     }
     const int lane = threadIdx.x & 63;
-    // A sparse batch (fuse_cells_kernel's): its light tiles are work items of fuse_wave_kernel, one wave each.  The item
-    // carries what the wave would otherwise look up in a chain of dependent loads: first record, count, tile origin.
-    if (tile_mode == MODE_CELLS && (M.light_max > 0 || M.medium_max > 0)) {
-#pragma unroll
-        for (int team = 0; team < 2; ++team) {           // 0: one wave per tile, 1: four waves
-            const bool mine = n > 0 && (team == 0 ? n <= M.light_max : n <= M.medium_max);
-            const unsigned long long m = __ballot(mine);
-            if (m == 0) continue;
-            int base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&ticket[team == 0 ? LIGHT_COUNT : MEDIUM_COUNT], __popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1, 64);
-            if (mine) {
-                const int tz = t % LP.nt2, ty = (t / LP.nt2) % LP.nt1, tx = t / (LP.nt2 * LP.nt1);
-                M.light[(team == 0 ? 0 : n_tiles) + base + __popcll(m & ((1ull << lane) - 1ull))] =
-                    make_int4(t, cursor[t * G], n, (tx << LP.s0) | ((ty << LP.s1) << 10) | ((tz << LP.s2) << 20));
-                n = 0;                                   // not listed for the tile kernel
-            }
+    if (tile_mode == MODE_CELLS) {
+        // fuse_cells_kernel's list: fine load classes; a work item carries what the kernel would otherwise look up in a
+        // chain of dependent loads: first entry, count, tile origin.  The block's tiles are ranked per class in LDS, so the
+        // block issues ONE returning global atomic per class it holds (all in flight together).
+        __shared__ int hist[CELL_CLASSES], hbase[CELL_CLASSES];
+        if (threadIdx.x < CELL_CLASSES) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const int fc = n > 0 ? cell_class(n) : -1;
+        int rank = 0;
+        if (fc >= 0) rank = atomicAdd(&hist[fc], 1);
+        __syncthreads();
+        if (threadIdx.x < CELL_CLASSES && hist[threadIdx.x] > 0) hbase[threadIdx.x] = atomicAdd(&ticket[CELL_COUNT + threadIdx.x], hist[threadIdx.x]);
+        __syncthreads();
+        if (fc >= 0) {
+            const int tz = t % LP.nt2, ty = (t / LP.nt2) % LP.nt1, tx = t / (LP.nt2 * LP.nt1);
+            M.items4[(size_t)fc * n_tiles + hbase[fc] + rank] =
+                make_int4(t, cursor[t * G], n, (tx << LP.s0) | ((ty << LP.s1) << 10) | ((tz << LP.s2) << 20));
         }
+        return;
     }
-    const int cls = tile_class(n);
+    // (tile-local entries are contributions, ~4.5 per point and tile: the load classes keep their meaning in points)
+    const int cls = tile_class(LP.meta ? n >> 2 : n);
     for (int c = 0; c < TILE_CLASSES; ++c) {
         const bool mine = n > 0 && cls == c;
         const unsigned long long m = __ballot(mine);
@@ -1337,6 +1327,9 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 constexpr int DENSE_SV = 7;               // 4 x 4 x 8 tiles
 constexpr int DENSE_FX = 40;              // fraction bits of the deltas
 constexpr int DENSE_MAX_CHUNKS = 32;
+#ifndef EBX_DEF
+#define EBX_DEF 16
+#endif
 
 // META: the records are in the tile-local meta format (sequential frames; class id and frame in the record, no aux words)
 template <int KIND, int MAXT, bool META, bool STAMPS = false>
@@ -1417,13 +1410,20 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
     int tile = misc[0];
     if (tile < 0) return;
 
-    uint4 pre[EB];
+    // META: the tile's entries are 8-byte contributions (one per corner inside the tile: make_contribution), else
+    // 16-byte point records + class-id words
+    typedef typename std::conditional<META, uint2, uint4>::type Rec;
+    // entries a thread of a big tile has in flight per trip: a contribution is one corner's work (a record was eight), so
+    // sixteen of them are requested together (room batch, kernel alone: 2 per trip 2.14 ms, 4: 1.53, 8: 1.38, 16: 1.30)
+    constexpr int EBX = META ? EBX_DEF : EB;
+    const Rec *recs = reinterpret_cast<const Rec *>(P.rec);
+    Rec pre[EB];
     uint32_t prex[EB];
-    auto prefetch_entries = [&](int ta, int tb, uint4 (&q)[EB], uint32_t (&qx)[EB]) {
+    auto prefetch_entries = [&](int ta, int tb, Rec (&q)[EB], uint32_t (&qx)[EB]) {
 #pragma unroll
         for (int j = 0; j < EB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
             const int e = min(ta + tid + j * NT, tb - 1);
-            q[j] = P.rec[e];
+            q[j] = recs[e];
             qx[j] = (KIND == 1 && !META) ? P.aux[e] : 0u;
         }
     };
@@ -1466,15 +1466,20 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
             MF_STAMP(1)
 
             // ---- pass 1: W, S2 of every (voxel, frame) cell of the chunk
-            auto p1_record = [&](const uint4 &r) {
-                const int f = (META ? meta_frame(r) : rec_group(r)) - f_base;
-                unsigned long long *cell = A + (size_t)f * TVP * 2;
-                auto add = [&](int, int v, float w) {
+            auto p1_record = [&](const Rec &r) {
+                if constexpr (META) {
+                    unsigned long long *cell = A + (size_t)((int)((r.x >> 15) & 255u) - f_base) * TVP * 2;
+                    const int v = (int)(r.x & 127u);
+                    const float w = __uint_as_float(r.y);
                     atomicAdd(&cell[2 * v], to_fixed(w, fx_c));
                     atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
-                };
-                if (META) meta_corners_idx<2, 3>(r, add);
-                else for_corners_idx(P, r, o0, o1, o2, add);
+                } else {
+                    unsigned long long *cell = A + (size_t)(rec_group(r) - f_base) * TVP * 2;
+                    for_corners_idx(P, r, o0, o1, o2, [&](int, int v, float w) {
+                        atomicAdd(&cell[2 * v], to_fixed(w, fx_c));
+                        atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
+                    });
+                }
             };
             // A small tile (all its records fit the registers fetched a tile ahead) is taken from there, in
             // straight-line code.  A big tile is dealt in SEGMENTS: thread t walks records [t * S, (t + 1) * S) of
@@ -1494,12 +1499,12 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
                     if (e >= ea && e < eb) p1_record(pre[j]);
                 }
             } else {
-                for (int e = my0; e < my1; e += EB) {
-                    uint4 r[EB];
+                for (int e = my0; e < my1; e += EBX) {
+                    Rec r[EBX];
 #pragma unroll
-                    for (int j = 0; j < EB; ++j) r[j] = P.rec[min(e + j, my1 - 1)];
+                    for (int j = 0; j < EBX; ++j) r[j] = recs[min(e + j, my1 - 1)];
 #pragma unroll
-                    for (int j = 0; j < EB; ++j)
+                    for (int j = 0; j < EBX; ++j)
                         if (e + j < my1) p1_record(r[j]);
                 }
             }
@@ -1575,14 +1580,21 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
             // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1): the t_f of a record's corners are
             // read together (a corner outside the tile reads that of one inside), then integer atomics
             {
-                auto p3_record = [&](const uint4 &r, uint32_t x) {
-                    const unsigned long long *cell = A + (size_t)((META ? meta_frame(r) : rec_group(r)) - f_base) * TVP * 2;
+                auto p3_record = [&](const Rec &r, uint32_t x) {
+                    if constexpr (META) {
+                        const unsigned long long *cell = A + (size_t)((int)((r.x >> 15) & 255u) - f_base) * TVP * 2;
+                        const int v = (int)(r.x & 127u);
+                        const float w = __uint_as_float(r.y), term = (w * w) * klow(cell, 2 * v);
+                        unsigned long long m = to_fixed(term, 182 - DENSE_FX);
+                        if (m == 0ull && term > 0.0f) m = 1ull;
+                        if (m != 0ull) atomicAdd(&Di[KIND == 0 ? v : v * C + (int)x], m);
+                    } else {
+                    const unsigned long long *cell = A + (size_t)(rec_group(r) - f_base) * TVP * 2;
                     int vi[8];
                     float qv[8];
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
-                    if (META) meta_corners_idx<2, 3>(r, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
-                    else for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+                    for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
                     int vf = 0;
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
@@ -1596,26 +1608,27 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
                             if (m == 0ull && term > 0.0f) m = 1ull;
                             if (m != 0ull) atomicAdd(&Di[KIND == 0 ? vi[cc] : vi[cc] * C + (int)x], m);
                         }
+                    }
                 };
                 if (!big) {
 #pragma unroll
                     for (int j = 0; j < EB; ++j) {
                         const int e = t_s + tid + j * NT;
-                        const uint32_t x = META ? meta_label(pre[j]) : prex[j];
+                        const uint32_t x = META ? (pre[j].x >> 7) & 255u : prex[j];
                         if (e >= ea && e < eb && (KIND == 0 || x < (uint32_t)C)) p3_record(pre[j], x);
                     }
                 } else {
-                    for (int e = my0; e < my1; e += EB) {
-                        uint4 r[EB];
-                        uint32_t x[EB];
+                    for (int e = my0; e < my1; e += EBX) {
+                        Rec r[EBX];
+                        uint32_t x[EBX];
 #pragma unroll
-                        for (int j = 0; j < EB; ++j) {
+                        for (int j = 0; j < EBX; ++j) {
                             const int q = min(e + j, my1 - 1);
-                            r[j] = P.rec[q];
-                            x[j] = KIND != 1 ? 0u : META ? meta_label(r[j]) : P.aux[q];
+                            r[j] = recs[q];
+                            x[j] = KIND != 1 ? 0u : META ? (r[j].x >> 7) & 255u : P.aux[q];
                         }
 #pragma unroll
-                        for (int j = 0; j < EB; ++j)
+                        for (int j = 0; j < EBX; ++j)
                             if (e + j < my1 && (KIND == 0 || x[j] < (uint32_t)C)) p3_record(r[j], x[j]);
                     }
                 }
@@ -1666,13 +1679,12 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
 }
 
 // ----------------------------------------------------------------------------
-// tile kernel for sparse frames (class ids / ones): compact (voxel, frame) cells
+// tile kernel for sparse frames (class ids / ones): compact (voxel, frame) cells over CONTRIBUTIONS
 // ----------------------------------------------------------------------------
-// A batch of unrelated frames (SURVEY distribution A) puts ~5 records of a frame into a 4 x 4 x 8 tile: of the
-// 128 x 64 (voxel, frame) pairs of a tile only ~600 receive anything.  fuse_tiles_kernel walks such a tile in
-// chunks of a few frames with dense per-frame accumulators (46 barrier-delimited phases per tile, each with a
-// handful of busy lanes); this kernel takes ALL frames of the tile at once:
-//   mask    every record ORs its frame's bit into a 64-bit mask per voxel (one integer LDS atomic per corner);
+// A batch of unrelated frames (SURVEY distribution A) puts ~5 points of a frame into a 4 x 4 x 8 tile: of the
+// 128 x 64 (voxel, frame) pairs of a tile only ~430 receive anything.  fuse_tiles_kernel walks such a tile in
+// chunks of a few frames with dense per-frame accumulators; this kernel takes ALL frames of the tile at once:
+//   mask    every contribution ORs its frame's bit into a 64-bit mask per voxel;
 //   scan    cell index of (voxel v, frame f) = cellbase[v] + popcount(mask[v] & bits below f): the cells that
 //           exist are numbered densely, voxel-major, frames ascending inside a voxel;
 //   pass 1  W, S2 of every cell as 64-bit fixed-point integer atomics (exact, order independent);
@@ -1682,237 +1694,220 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
 //   pass 3  D[v][class] += t_f w^2 as 32-bit fixed point (31 fraction bits: every term and every sum of terms of
 //           a (voxel, class) lies in [0, 1 + eps]; a positive term below one unit adds one unit so that
 //           "non-zero" survives): integer atomics that return nothing;
-//   final   rows out: old * prod a + D, the old rows loaded into registers (they never enter LDS).
-// Every pass takes all records of the tile at once; records are in the tile-local meta format (make_meta_record),
-// so a pass decodes one in ~40 instructions and reads the LDS words of all eight corners before it waits.
-// All global loads of a tile (the next tile's first records, the look-ups of the tiles after it, the old rows)
-// are issued together at the start of the final pass and waited for once: no pass has a load in flight, so the
-// compiler puts no vmcnt wait into them (it tracks the counter exactly only in straight-line code).
+//   final   rows out: old * prod a + D (two floats per instruction), the old rows loaded into registers; a float4
+//           whose voxels received nothing is not written back.
+// The passes read CONTRIBUTIONS (scatter_kernel, make_contribution): one 8-byte word per (point, corner inside the
+// tile) with the tile-local voxel, class id, frame and the corner weight.  Rounds 2-3 stored one 16-byte record per
+// (point, tile) and every pass decoded it and walked its eight corners (4.55 of them inside the tile on average):
+// ~700 instructions per 64 records and pass, on SIMDs that are busy issuing ~90 % of the time
+// (SQ_ACTIVE_INST_ANY, profiles/r03_sq_counters.txt).  Expanded once where the geometry is at hand anyway, a pass
+// is ~15 instructions per 64 contributions with every lane busy.
+// A tile's first 1,024 contributions are fetched one tile ahead and stay in registers for all passes.  The work
+// list holds items {tile, first contribution, count, origin} (tile_list_kernel): ticket -> item is the only
+// dependent look-up, drawn two tiles ahead by thread 0.
 // A tile whose frames need more cells than fit (tiles next to the cameras) keeps its masks and takes its frames
 // in several windows; a later window multiplies the deltas by its own prod a.  Calls of more than 64 frames take
 // 64 at a time the same way.  All sums are integers: results are run-to-run identical.
 // tile_list_kernel picks this kernel or fuse_dense_kernel from the call's density; both work on 4 x 4 x 8 tiles.
-constexpr int CELLS_FX = 31;              // fraction bits of the deltas
-constexpr int CELLS_MISC = 32 + 64;       // look-up words + per-frame cell counts of a window search
-#ifndef CELLS_RB_DEF
-#define CELLS_RB_DEF 256
-#endif
-#ifndef CELLS_SCANALL_DEF
-#define CELLS_SCANALL_DEF 0
-#endif
-#ifndef CELLS_CICACHE_DEF
-#define CELLS_CICACHE_DEF 1
-#endif
-#ifndef CELLS_EARLY_DEF
-#define CELLS_EARLY_DEF 0
-#endif
-constexpr bool CELLS_EARLY = CELLS_EARLY_DEF != 0;   // the tile's loads are issued at its start (else at the start of its final pass)
-constexpr int CELLS_RB = CELLS_RB_DEF;    // records of a tile kept in LDS per 256 threads (its first ones, fetched a tile ahead)
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (six dependent VALU
+// instructions; the __shfl_up ladder is six ds_bpermute round trips of ~100 cycles each, on the critical path of
+// every tile).
+__device__ __forceinline__ int wave_inclusive_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);      // row_shr:8: inclusive inside each row of 16
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
 
-template <int KIND, int S0, int S1, int S2, int NT, int F4, bool STAMPS = false>   // F4: float4s per lane and tile row (ceil(C 2^S2 / 256))
-__global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_cells_kernel(TileParams P)
+constexpr int CELLS_FX = 31;              // fraction bits of the deltas
+constexpr int CELLS_CR = 4;               // contributions per thread kept in registers (fetched a tile ahead)
+
+template <int KIND, int F4, bool STAMPS = false>   // F4: float4s per thread and tile (ceil(32 C / 256))
+__global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
 {
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-    constexpr int SV = S0 + S1 + S2, TV = 1 << SV, NW = NT / 64, CEB = CELLS_RB / 256, RB = NT * CEB;
-    constexpr int N_ROWS = TV >> S2, RPW = (N_ROWS + NW - 1) / NW;          // tile rows, rows per wave
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    constexpr int TV = 128, NT = 256;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = P.C, G = P.G, CAP = P.cells_cap;
-    const unsigned n_el = (unsigned)TV * (unsigned)C;
-    // LDS: per voxel {mask (u64), cell base, prod a}, cells, deltas, look-up words
-    struct Vox { unsigned long long mask; int cbase; float atot; };
-    Vox *vox = reinterpret_cast<Vox *>(smem);                                        // [TV + 1] ([TV].cbase = cells in use)
-    unsigned long long *cells = reinterpret_cast<unsigned long long *>(vox + TV + 1);   // [CAP + 1][2] W, S2; then (g, a); then t_f
-    uint4 *recbuf = reinterpret_cast<uint4 *>(cells + (size_t)(CAP + 1) * 2);        // [RB] the tile's first records: thread t owns slots t + j NT
-    uint4 *cibuf = recbuf + RB;                                                      // [RB] the cells of those records' corners (pass 1 -> pass 3), 16 bits each
-    unsigned *Du = reinterpret_cast<unsigned *>(cibuf + RB);                         // [TV][C] deltas, units of 2^-CELLS_FX
-    int *misc = reinterpret_cast<int *>(Du + n_el);
-    constexpr int M_TILE = 0, M_NEXT = 1, M_FIT = 2, M_EA = 3 /* [2] */, M_OFF = 6 /* [2] */, M_OFFN = 8 /* [2] */,
-                  M_CLS = 12 /* [TILE_CLASSES] */, M_CNT = 32 /* [64] inclusive per-frame cell counts */;
-    static_assert(M_CLS + TILE_CLASSES <= 32, "misc words");
+    const unsigned n_el = (unsigned)TV * (unsigned)C, n4 = n_el >> 2;
+    // LDS: per voxel frame masks and cell bases (arrays of their own: a lane's word is its voxel's bank), prod a;
+    // cells W / S2; deltas; look-up words
+    unsigned *vm = reinterpret_cast<unsigned *>(smem);                          // [4][128] mask of frames 0..31, cell base, mask 32..63, cell base of frame 32
+    float *atot = reinterpret_cast<float *>(vm + 4 * TV);                       // [128]
+    int *misc = reinterpret_cast<int *>(atot + TV);                             // [128]
+    unsigned long long *Wc = reinterpret_cast<unsigned long long *>(misc + 128);   // [CAP + 1] W, then (g, a), then t_f
+    unsigned long long *Sc = Wc + CAP + 1;                                      // [CAP + 1] S2
+    unsigned *Du = reinterpret_cast<unsigned *>(Sc + CAP + 1);                  // [128][C] deltas, units of 2^-CELLS_FX
+    constexpr int M_TOT = 0, M_FIT = 1, M_EA = 2 /* [2] */, M_CS = 8 /* [CELL_CLASSES + 1] list position of the classes' first tiles */,
+                  M_CNT = 64 /* [64] inclusive per-frame cell counts */;
+    static_assert(M_CS + CELL_CLASSES + 1 <= M_CNT, "look-up words");
+    const uint2 *rec2 = reinterpret_cast<const uint2 *>(P.rec);
     const int fx_c = 182 - P.fx_shift;
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
     const float du_inv = __uint_as_float((unsigned)(127 - CELLS_FX) << 23);    // 2^-CELLS_FX
     const float du_scale = __uint_as_float((unsigned)(127 + CELLS_FX) << 23);  // 2^CELLS_FX
+    const float iw = P.iw;
 
     if (P.ticket[MODE_SLOT] != MODE_CELLS) return;                             // fuse_dense_kernel takes the call (uniform)
-    {
-        int listed = 0;
-#pragma unroll
-        for (int c = 0; c < TILE_CLASSES; ++c) listed += P.ticket[1 + c];
-        if (listed == 0) return;
+    // Work list position -> item; tile -1 past the end.  misc[M_CS + c] = list position of class c's first tile; a
+    // workgroup's positions only grow, so the class is found by walking on from the last one.
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < CELL_CLASSES; ++c) { misc[M_CS + c] = run; run += P.ticket[CELL_COUNT + c]; }
+        misc[M_CS + CELL_CLASSES] = run;
     }
-    // work list position -> tile id, -1 past the end: the class is found from the class sizes (LDS), then ONE load
-    // (a chain of conditional loads, one per class, makes the compiler wait for memory after each of them)
-    auto resolve = [&](int idx) {
-        int cls = -1, pos = 0, rest = idx;
-#pragma unroll
-        for (int c = 0; c < TILE_CLASSES; ++c) {
-            const int cc = misc[M_CLS + c];
-            if (cls < 0 && rest >= 0 && rest < cc) { cls = c; pos = rest; }
-            rest -= cc;
-        }
-        return cls >= 0 ? P.active[cls * P.n_tiles + pos] : -1;
+    __syncthreads();
+    int walk_c = 0;
+    auto fetch_item = [&](int idx) {
+        while (walk_c < CELL_CLASSES && idx >= misc[M_CS + walk_c + 1]) ++walk_c;      // (uniform)
+        int4 it = make_int4(-1, 0, 0, 0);
+        if (walk_c < CELL_CLASSES) it = P.light[(size_t)walk_c * P.n_tiles + (idx - misc[M_CS + walk_c])];   // (uniform; made scalar by `uniform` where it is first used)
+        return it;
     };
-    // first record of bucket k (after scatter_kernel cursor[k] is the END of bucket k); k <= n_tiles * G = n_keys
-    // whenever the tile id comes from the work list and the frame is <= G, so cursor[k - 1] is inside the scanned array
+    auto uniform = [](int4 it) {
+        it.x = __builtin_amdgcn_readfirstlane(it.x); it.y = __builtin_amdgcn_readfirstlane(it.y);
+        it.z = __builtin_amdgcn_readfirstlane(it.z); it.w = __builtin_amdgcn_readfirstlane(it.w);
+        return it;
+    };
+    // first contribution of bucket k (after scatter_kernel cursor[k] is the END of bucket k)
     auto bucket_start = [&](int k) { return k > 0 ? P.cursor[k - 1] : 0; };
-    auto tile_range = [&](int t) {         // lane 0: first record of tile t, lane 1: one past its last (wave 0)
-        int o = 0;
-        if (t >= 0 && tid <= 1) o = bucket_start((t + tid) * G);
-        return o;
-    };
-    // Look-ups of the tiles ahead (ticket -> work list entry -> record range: dependent global round trips) are
-    // made by wave 0, one stage per tile, at the start of the final pass.
-    int tk_next = 0, tk_end = 0, act_pend = -1, rng_tile = -1, rng_off = 0, nx_tile = -1, nx_off = 0;
-    constexpr int TK_BATCH = 8;            // tickets drawn at a time: the returning atomic is a memory round trip that has to be waited for
-    if (tid == 0)
-#pragma unroll
-        for (int c = 0; c < TILE_CLASSES; ++c) misc[M_CLS + c] = P.ticket[1 + c];
-    for (int i = tid; i < (TV + 1) * 2 + (CAP + 1) * 2; i += NT) reinterpret_cast<unsigned long long *>(smem)[i] = 0ull;   // voxel words, cells
+    for (int i = tid; i < 4 * TV; i += NT) vm[i] = 0u;
+    for (int i = tid; i < 2 * (CAP + 1); i += NT) Wc[i] = 0ull;
     for (unsigned i = tid; i < n_el; i += NT) Du[i] = 0u;
+    // The list is heaviest first (eight load classes); workgroup b of n takes positions b, b + n, b + 2 n, ...: every
+    // workgroup gets its share of every class, in the same order, and no position depends on a returning atomic (a
+    // ticket per tile was a memory round trip at every tile's start: the compiler waits for a value that comes out of a
+    // divergent branch where the branches join).
+    const int nb = gridDim.x;
+    int lp = blockIdx.x;                                 // list position of the current item
+    int4 item = uniform(fetch_item(lp)), item_n = uniform(fetch_item(lp + nb));
+    if (item.x < 0) return;
     __syncthreads();
-    if (tid < 64) {
-        // this tile, the next one (both published in LDS), the two after it (wave 0's registers), the work list
-        // entry of the one after those (load in flight) and one more ticket (atomic in flight).  Only the first
-        // item of a workgroup is dealt statically (list position b: the list is heaviest first, so every
-        // workgroup starts on one of the n heaviest tiles); everything else is drawn from the counter, which
-        // tile_list_kernel starts at n.  (Four static items per workgroup, as fuse_tiles_kernel deals them, hand
-        // some of the workgroups four of the few hundred tiles that hold a quarter of all records.)
-        const int b = blockIdx.x;
-        int tk = tid == 0 ? atomicAdd(P.ctr, TK_BATCH) : 0;    // a workgroup's list positions ascend, so "past the end" for
-        tk = __shfl(tk, 0, 64);                                 // one item implies it for all later ones
-        tk_next = tk + 4; tk_end = tk + TK_BATCH;
-        const int t0 = resolve(b), t1 = resolve(tk);
-        const int o0 = tile_range(t0), o1 = tile_range(t1);
-        if (tid == 0) { misc[M_TILE] = t0; misc[M_NEXT] = t1; }
-        if (tid <= 1) { misc[M_OFF + tid] = o0; misc[M_OFFN + tid] = o1; }
-        nx_tile = resolve(tk + 1);
-        nx_off = tile_range(nx_tile);
-        rng_tile = resolve(tk + 2);
-        rng_off = tile_range(rng_tile);
-        act_pend = resolve(tk + 3);
+
+    // final pass: float4 j = tid + 256 i of the tile image [16 rows][8 voxels][C]: byte offset from the tile's first
+    // voxel, first voxel and how many of its four floats belong to that voxel (tile-invariant)
+    const unsigned rsb = (unsigned)P.size2 * (unsigned)C * 4u;                  // bytes between map rows (x + 1)
+    unsigned pk[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+        const unsigned j = tid + 256u * i, c2 = 2u * C;
+        const unsigned row = j / c2, col4 = j - row * c2;                  // (once per kernel)
+        const unsigned e = 4u * col4, svr = div_magic(e, P.magicC), rem = e - svr * C;
+        const unsigned cross = min(4u, (unsigned)C - rem);
+        pk[i] = ((row & 15u) * 8u + svr) | (cross << 7) | ((row & 15u) << 10) | ((j < n4 ? 1u : 0u) << 14) | (col4 << 15);
     }
-    __syncthreads();
-    int tile = __builtin_amdgcn_readfirstlane(misc[M_TILE]);
-    if (tile < 0) return;
-
-    // the first CEB x NT records of a tile are fetched one tile ahead and stay in registers for all passes
-    static_assert(CEB == 1 || CEB == 2, "one or two records per thread are fetched ahead");
-    uint4 pre0, pre1 = make_uint4(0u, 0u, 0u, 0u);      // (named registers: an array indexed in a lambda ends up in scratch memory)
-    auto prefetch_entries = [&](int ta, int tb) {       // unconditional (clamped) loads
-        pre0 = P.rec[min(ta + tid, tb - 1)];
-        if (CEB == 2) pre1 = P.rec[min(ta + tid + NT, tb - 1)];
-    };
-    auto tile_origin = [&](int t, int &o0, int &o1, int &o2) {
-        const int tz = t % P.nt2, ty = (t / P.nt2) % P.nt1, tx = t / (P.nt2 * P.nt1);
-        o0 = tx << S0; o1 = ty << S1; o2 = tz << S2;
-    };
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    // exclusive scan of the voxels' cell counts inside the frame window `wm` (wave 0, TV / 64 voxels per lane)
-    // (every wave runs it and writes the same words: what a wave reads afterwards it has written itself, so no barrier
-    // is needed between the scan and the pass that follows)
-    auto scan_cells = [&](unsigned long long wm) {
-        if (!CELLS_SCANALL_DEF && tid >= 64) return;
-        constexpr int VPL = TV / 64;
-        int n[VPL], tot = 0;
-#pragma unroll
-        for (int q = 0; q < VPL; ++q) { n[q] = __popcll(vox[VPL * lane + q].mask & wm); tot += n[q]; }
-        int inc = tot;
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
-        int ex = inc - tot;
-#pragma unroll
-        for (int q = 0; q < VPL; ++q) { vox[VPL * lane + q].cbase = ex; ex += n[q]; }
-        if (lane == 63) vox[TV].cbase = inc;
+    auto row_offset = [&](unsigned p) {                 // bytes from the tile's first voxel (one register per slot is kept, not two)
+        const unsigned row = (p >> 10) & 15u;
+        return ((row >> 2) * (unsigned)P.size1 + (row & 3u)) * rsb + (p >> 15) * 16u;
     };
 
-    prefetch_entries(misc[M_OFF], misc[M_OFF + 1]);
-    recbuf[tid] = pre0;
-    if (CEB == 2) recbuf[tid + NT] = pre1;
-    const unsigned row_len = (unsigned)C << S2, row4 = row_len >> 2;
-    const size_t row_stride = (size_t)P.size2 * C;                       // floats between map rows (x + 1)
+    // The first CELLS_CR x 256 contributions of a tile stay in registers for all passes; they are requested at the start
+    // of the tile BEFORE, together with that tile's rows, and taken over at its end: no load whose result is still
+    // awaited crosses the loop's back edge (where the compiler, which tracks the counter exactly only in straight-line
+    // code, would wait for everything in flight - the rows just requested included).
+    uint2 cache[CELLS_CR], cache_n[CELLS_CR];
+    auto prefetch = [&](int first, int n, uint2 (&q)[CELLS_CR]) {       // unconditional (clamped) loads
+#pragma unroll
+        for (int j = 0; j < CELLS_CR; ++j) q[j] = rec2[first + min(tid + NT * j, max(n - 1, 0))];
+    };
+    prefetch(item.y, item.z, cache);
+    auto base_of = [&](unsigned org) {                   // address of the tile's first voxel
+        const int o0 = org & 1023u, o1 = (org >> 10) & 1023u, o2 = org >> 20;
+        return reinterpret_cast<const char *>(P.map + ((size_t)o0 * P.size1 + o1) * ((size_t)P.size2 * C) + (size_t)o2 * C);
+    };
+    auto rows_inside = [&](unsigned org) {               // bit i: float4 slot i lies inside the map (a map whose extents are no multiples of four)
+        const int o0 = org & 1023u, o1 = (org >> 10) & 1023u;
+        unsigned in = 0xffffffffu;
+        if (o0 + 4 > P.size0 || o1 + 4 > P.size1) {     // (uniform, rare)
+            in = 0u;
+#pragma unroll
+            for (int i = 0; i < F4; ++i) {
+                const unsigned row = (pk[i] >> 10) & 15u;
+                if (o0 + (int)(row >> 2) < P.size0 && o1 + (int)(row & 3u) < P.size1) in |= 1u << i;
+            }
+        }
+        return in;
+    };
+    auto load_rows = [&](const char *base, unsigned in, bool any, v4f (&q)[F4]) {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            q[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            if (any && (unsigned)(i * NT) < n4) {           // (uniform)
+                unsigned pki = pk[i];
+                asm volatile("" : "+v"(pki));               // (see the final pass)
+                if (((pki >> 14) & 1u) && ((in >> i) & 1u)) q[i] = *reinterpret_cast<const v4f *>(base + (size_t)row_offset(pki));
+            }
+        }
+    };
 
     while (true) {
-        int o0, o1, o2;
-        tile_origin(tile, o0, o1, o2);
-        const int t_a = __builtin_amdgcn_readfirstlane(misc[M_OFF]), t_b = __builtin_amdgcn_readfirstlane(misc[M_OFF + 1]);
-        const int tile_n = __builtin_amdgcn_readfirstlane(misc[M_NEXT]);
-        const int tn_a = __builtin_amdgcn_readfirstlane(misc[M_OFFN]), tn_b = __builtin_amdgcn_readfirstlane(misc[M_OFFN + 1]);
-        const unsigned long long t_tile = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
-        MF_STAMP(0)
-        // The tile's first RB records were fetched one tile ahead (registers); they go to this thread's own LDS slots
-        // (no other thread reads them: no barrier) so that every pass can take its records in ONE loop with ONE copy
-        // of the corner code: slot k < RB from LDS, the rest of a heavy tile from memory.  (Kept in registers, the
-        // copy needs a code path of its own per pass, and a select between the two makes the compiler spill it to
-        // scratch memory and read both through flat loads.)
-        auto for_records = [&](int ea, int eb, auto body) {
-            const int k1 = eb - t_a;
-            int k = (ea - t_a) / NT * NT + tid;                                // k: index inside the tile; k < RB is uniform
-            uint4 gn = make_uint4(0u, 0u, 0u, 0u);                              // a heavy tile's record of the NEXT trip:
-            if (k >= RB && k < k1) gn = P.rec[t_a + k];                         // loaded one trip ahead, so that the
+        const int tile = item.x, t_a = item.y, t_b = item.y + item.z;
+        const unsigned org = (unsigned)item.w;
+        const int tile_n = item_n.x;
+        // ---- all global loads of the tile: the item after the next (scalar), the next tile's first contributions, this
+        // tile's old rows (used in the final pass: the passes in between neither wait for them nor need the registers)
+        MF_STAMP(7)
+        const int4 item_n2 = fetch_item(lp + 2 * nb);
+        prefetch(item_n.y, item_n.z, cache_n);
+        // (the NEXT tile's rows instead, held in 28 more registers for a whole tile, were measured too: 1.93 against 1.88 ms -
+        // the wait moves from the final pass to the point where the loads are issued: the memory pipeline, not the round
+        // trip, is what the rows wait for)
+        const char *tile_base = base_of(org);
+        v4f oldv[F4];
+        const unsigned rows_in = rows_inside(org);
+        load_rows(tile_base, rows_in, true, oldv);
+        // the contributions [ea, eb) of this tile: the cached ones from registers, the rest of a heavy tile from
+        // memory (one trip ahead, so that the round trip runs beside the body)
+        auto for_contribs = [&](int ea, int eb, auto body) {
+#pragma unroll
+            for (int j = 0; j < CELLS_CR; ++j) {
+                const int k = t_a + tid + NT * j;
+                if (t_a + NT * j < eb) {                                        // (uniform)
+                    // (the empty asm hides from the compiler that the word is the same in every pass: it would decode all
+                    // four once and hold the fields in registers across the tile)
+                    uint2 c = cache[j];
+                    asm volatile("" : "+v"(c.x), "+v"(c.y));
+                    if (k >= ea && k < eb) body(c);
+                }
+            }
+            // (four loads per thread in flight, one trip ahead: with one, every trip of 256 contributions waited a whole
+            // memory round trip - ~1.3 M trips per launch, the bulk of the kernel's time in round 4's first version)
+            int k = max(ea, t_a + NT * CELLS_CR);
+            k += ((tid - k) & (NT - 1));                                        // the first k' >= k with k' = tid (mod 256): coalesced trips
+            if (k < eb) {
+                uint2 nx[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nx[q] = rec2[min(k + NT * q, eb - 1)];
 #pragma unroll 1
-            for (; k < k1; k += NT) {                                           // memory round trip runs beside the body
-                uint4 r;
-                // (the empty asm keeps the two sources apart: merged, they become one flat load through a selected pointer)
-                if (k < RB) { r = recbuf[k]; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
-                else { r = gn; asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
-                const int kn = k + NT;
-                if (kn >= RB && kn < k1) gn = P.rec[t_a + kn];
-                if (t_a + k >= ea) body(r, k);
-            }
-        };
-        // cell of every corner of a record (a corner outside the tile reads voxel 0: the reads of all eight corners
-        // are issued before the first is used, the atomics that follow are masked)
-        auto corner_cells = [&](const MetaCorners<S1, S2> &m, unsigned long long wbelow, int (&ci)[8]) {
-            uint4 x[8];                                     // {mask lo, mask hi, cell base, prod a}: one 16-byte read per corner
+                for (; k < eb; k += 4 * NT) {
+                    uint2 c[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) x[c] = reinterpret_cast<const uint4 *>(vox)[(m.in8 >> c) & 1u ? m.v[c] : 0];
-            const unsigned wlo = (unsigned)wbelow, whi = (unsigned)(wbelow >> 32);
+                    for (int q = 0; q < 4; ++q) c[q] = nx[q];
+                    if (k + 4 * NT < eb) {                                      // (per thread; clamped: no branch per load)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) ci[c] = (int)x[c].z + __popc(x[c].x & wlo) + __popc(x[c].y & whi);
-        };
-
-        // All global loads of a tile: look-ups of the tiles ahead (wave 0), the next tile's first records, this tile's
-        // old rows (a wave takes whole rows: row, wave and the row's address are scalars; rows outside the map read row 0)
-        int p_rng_tile = -1, p_rng_off = 0, p_act = -1;
-        v4f oldv[RPW][F4];
-        float *grow[RPW];
-        auto issue_lookups = [&]() {                            // (at a point where every older load of the wave has landed)
-            if (tid < 64) {
-                p_rng_tile = act_pend;                           // (issued one tile ago, landed with that tile's rows)
-                p_rng_off = tile_range(p_rng_tile);
-                if (tk_next == tk_end) {                         // (uniform) a new batch of tickets, once per TK_BATCH tiles
-                    int tk = tid == 0 ? atomicAdd(P.ctr, TK_BATCH) : 0;
-                    tk_next = __shfl(tk, 0, 64);
-                    tk_end = tk_next + TK_BATCH;
-                }
-                p_act = resolve(tk_next++);
-            }
-        };
-        auto issue_loads = [&]() {
-            if (tile_n >= 0) prefetch_entries(tn_a, tn_b);       // (the record registers are free: their content is in LDS)
+                        for (int q = 0; q < 4; ++q) nx[q] = rec2[min(k + NT * (4 + q), eb - 1)];
+                    }
 #pragma unroll
-            for (int q = 0; q < RPW; ++q) {
-                const int r = wave + q * NW;
-                const int l1 = r & ((1 << S1) - 1), l0 = r >> S1;
-                const bool in = r < N_ROWS && o0 + l0 < P.size0 && o1 + l1 < P.size1;
-                grow[q] = in ? P.map + ((size_t)(o0 + l0) * P.size1 + (o1 + l1)) * row_stride + (size_t)o2 * C : nullptr;
-#pragma unroll
-                for (int f = 0; f < F4; ++f) {
-                    const unsigned i4 = lane + 64 * f;
-                    oldv[q][f] = reinterpret_cast<const v4f *>(grow[q] ? grow[q] : P.map)[i4 < row4 ? i4 : 0];
+                    for (int q = 0; q < 4; ++q)
+                        if (k + NT * q < eb) body(c[q]);
                 }
             }
         };
-        if (CELLS_EARLY) issue_loads();
 
+        MF_STAMP(0)
         bool first = true;
         for (int F = 0; F < G; F += 64) {                   // at most 64 frames share the voxels' masks
             const int nf = min(64, G - F);
             int sa = t_a, sb = t_b;
-            if (G > 64) {                                   // part of the tile's frames: look its record range up
+            if (G > 64) {                                   // part of the tile's frames: look its range up
                 if (tid <= 1) misc[M_EA + tid] = bucket_start(tile * G + (tid == 0 ? F : F + nf));
                 __syncthreads();
                 sa = misc[M_EA]; sb = misc[M_EA + 1];
@@ -1920,28 +1915,35 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
             }
             if (sa >= sb) continue;                         // (uniform)
             // ---- mask pass: which of these frames touch which voxel
-            for_records(sa, sb, [&](const uint4 &r, int) {
-                const MetaCorners<S1, S2> m(r);
-                const unsigned long long bit = 1ull << (meta_frame(r) - F);
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if ((m.in8 >> c) & 1u) atomicOr(&vox[m.v[c]].mask, bit);
+            for_contribs(sa, sb, [&](const uint2 &c) {
+                const unsigned f = ((c.x >> 15) & 255u) - (unsigned)F;
+                atomicOr(&vm[(f >> 5) * 256u + (c.x & 127u)], 1u << (f & 31u));
             });
-            barrier_keep_vm();
+            __syncthreads();
             MF_STAMP(1)
+            // exclusive scan of the voxels' cell counts inside the frame window wm (wave 0, two voxels per lane)
+            auto scan_cells = [&](unsigned long long wm) {
+                if (tid >= 64) return;
+                const unsigned wl = (unsigned)wm, wh = (unsigned)(wm >> 32);
+                const int v = 2 * lane;
+                const int nl0 = __popc(vm[v] & wl), nl1 = __popc(vm[v + 1] & wl);
+                const int c0n = nl0 + __popc(vm[256 + v] & wh), c1n = nl1 + __popc(vm[256 + v + 1] & wh);
+                const int inc = wave_inclusive_scan(c0n + c1n);
+                const int ex = inc - (c0n + c1n);
+                vm[128 + v] = (unsigned)ex; vm[384 + v] = (unsigned)(ex + nl0);
+                vm[128 + v + 1] = (unsigned)(ex + c0n); vm[384 + v + 1] = (unsigned)(ex + c0n + nl1);
+                if (lane == 63) misc[M_TOT] = inc;
+            };
             scan_cells(~0ull);
-            // no workgroup barrier here (see scan_cells), but the compiler must not move the passes' 16-byte reads of the
-            // voxel words above the scan's 4-byte writes of the cell bases (different access types: it assumes no alias)
-            asm volatile("" ::: "memory");
-            if (!CELLS_SCANALL_DEF) barrier_keep_vm();
-            const bool split = vox[TV].cbase > CAP;         // (uniform) the cells of these frames do not fit at once
+            __syncthreads();
+            const bool split = misc[M_TOT] > CAP;           // (uniform) the cells of these frames do not fit at once
             if (split) {
                 // inclusive per-frame cell counts: a window is a run of frames whose cells fit
                 if (tid < 64) {
                     int cnt = 0;
-                    for (int v = 0; v < TV; ++v) cnt += (int)((vox[v].mask >> tid) & 1ull);
-                    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(cnt, o, 64); if (tid >= o) cnt += y; }
-                    misc[M_CNT + tid] = cnt;
+                    const unsigned *mw = vm + (tid >> 5) * 256;
+                    for (int v = 0; v < TV; ++v) cnt += (int)((mw[v] >> (tid & 31)) & 1u);
+                    misc[M_CNT + tid] = wave_inclusive_scan(cnt);
                 }
                 __syncthreads();
             }
@@ -1964,46 +1966,50 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                 }
                 MF_STAMP(2)
                 if (ea < eb) {
+                    const unsigned wl = (unsigned)wm, wh = (unsigned)(wm >> 32);
+                    // cell of a contribution: its voxel's base + the frames of the window below its own
+                    auto cell_of = [&](const uint2 &c) {
+                        const unsigned f = ((c.x >> 15) & 255u) - (unsigned)F, v = c.x & 127u;
+                        const unsigned *mw = vm + (f >> 5) * 256u;
+                        return (int)mw[128 + v] + __popc(mw[v] & (f >> 5 ? wh : wl) & ((1u << (f & 31u)) - 1u));
+                    };
                     // ---- pass 1: W, S2 of every cell
-                    for_records(ea, eb, [&](const uint4 &r, int k) {
-                        const MetaCorners<S1, S2> m(r);
-                        const int fl = meta_frame(r) - F;
-                        int ci[8];
-                        corner_cells(m, wm & ((1ull << fl) - 1ull), ci);
-                        if (CELLS_CICACHE_DEF && k < RB)         // kept for pass 3 (this thread's own slot)
-                            cibuf[k] = make_uint4((unsigned)ci[0] | (unsigned)ci[1] << 16, (unsigned)ci[2] | (unsigned)ci[3] << 16,
-                                                  (unsigned)ci[4] | (unsigned)ci[5] << 16, (unsigned)ci[6] | (unsigned)ci[7] << 16);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c)
-                            if ((m.in8 >> c) & 1u) {
-                                atomicAdd(&cells[2 * ci[c]], to_fixed(m.w[c], fx_c));
-                                atomicAdd(&cells[2 * ci[c] + 1], to_fixed(m.w[c] * m.w[c], fx_c));
-                            }
+                    for_contribs(ea, eb, [&](const uint2 &c) {
+                        const int ci = cell_of(c);
+                        const float w = __uint_as_float(c.y);
+                        atomicAdd(&Wc[ci], to_fixed(w, fx_c));
+                        atomicAdd(&Sc[ci], to_fixed(w * w, fx_c));
                     });
-                    barrier_keep_vm();
+                    __syncthreads();
                     MF_STAMP(3)
                     // ---- pass 2a: per cell g = iw / W, a = 1 - iw S2 / W (every thread takes cells)
-                    const int used = vox[TV].cbase;
+                    const int used = misc[M_TOT];
                     for (int i = tid; i < used; i += NT) {
-                        const float rW = __builtin_amdgcn_rcpf((float)cells[2 * i] * fx_inv);
-                        const float a = 1.0f - P.iw * (((float)cells[2 * i + 1] * fx_inv) * rW);
-                        float2 ga; ga.x = P.iw * rW; ga.y = a;
-                        *reinterpret_cast<float2 *>(cells + 2 * i) = ga;
+                        const float rW = __builtin_amdgcn_rcpf((float)Wc[i] * fx_inv);
+                        float2 ga; ga.x = iw * rW; ga.y = 1.0f - iw * (((float)Sc[i] * fx_inv) * rW);
+                        *reinterpret_cast<float2 *>(Wc + i) = ga;
+                        Sc[i] = 0ull;
                     }
-                    barrier_keep_vm();
+                    __syncthreads();
                     // ---- pass 2b: per voxel, cells from the last frame to the first: t_f = g_f prod_{f' > f} a_f';
                     // prod a over the window multiplies what the earlier windows left
                     if (tid < TV) {
-                        const int v = tid, cs = vox[v].cbase, ce = vox[v + 1].cbase;
+                        const int v = tid, cs = (int)vm[128 + v], cnt = __popc(vm[v] & wl) + __popc(vm[256 + v] & wh);
                         float run = 1.0f;
-                        for (int j = ce - 1; j >= cs; --j) {
-                            const float2 ga = *reinterpret_cast<const float2 *>(cells + 2 * j);
-                            reinterpret_cast<float *>(cells + 2 * j)[0] = ga.x * run;
-                            run *= ga.y;
+                        for (int j = cs + cnt - 1; j >= cs; j -= 4) {       // four cells per trip: their reads do not wait for each other
+                            float2 ga[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) ga[q] = *reinterpret_cast<const float2 *>(Wc + max(j - q, cs));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (j - q >= cs) {
+                                    reinterpret_cast<float *>(Wc + j - q)[0] = ga[q].x * run;
+                                    run *= ga[q].y;
+                                }
                         }
-                        if (first) vox[v].atot = run;
-                        else if (ce > cs) {
-                            vox[v].atot *= run;
+                        if (first) atot[v] = run;
+                        else if (cnt > 0) {
+                            atot[v] *= run;
                             for (int ch = 0; ch < C; ++ch) {
                                 const unsigned d = Du[v * C + ch];
                                 if (d != 0u) {
@@ -2014,472 +2020,79 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : NT == 512 ? 4 : 4)) void fuse_
                             }
                         }
                     }
-                    barrier_keep_vm();
+                    __syncthreads();
                     MF_STAMP(4)
-                    // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1)
-                    for_records(ea, eb, [&](const uint4 &r, int k) {
-                        const uint32_t x = meta_label(r);
-                        if (KIND == 1 && x >= (uint32_t)C) return;
-                        const MetaCorners<S1, S2> m(r);
-                        int ci[8];
-                        if (CELLS_CICACHE_DEF && k < RB) {       // (wave-uniform) the cells pass 1 found
-                            const uint4 q = cibuf[k];
-                            ci[0] = q.x & 0xffffu; ci[1] = q.x >> 16; ci[2] = q.y & 0xffffu; ci[3] = q.y >> 16;
-                            ci[4] = q.z & 0xffffu; ci[5] = q.z >> 16; ci[6] = q.w & 0xffffu; ci[7] = q.w >> 16;
-                        } else {
-                            const int fl = meta_frame(r) - F;
-                            corner_cells(m, wm & ((1ull << fl) - 1ull), ci);
-                        }
-                        float t[8];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) t[c] = klow(cells, 2 * ((m.in8 >> c) & 1u ? ci[c] : 0));
-#pragma unroll
-                        for (int c = 0; c < 8; ++c)
-                            if ((m.in8 >> c) & 1u) {
-                                const float term = (m.w[c] * m.w[c]) * t[c];
-                                unsigned q = (unsigned)(term * du_scale);
-                                if (q == 0u && term > 0.0f) q = 1u;
-                                if (q != 0u) atomicAdd(&Du[KIND == 0 ? m.v[c] : m.v[c] * C + (int)x], q);
-                            }
+                    // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1; an invalid class id adds nothing)
+                    for_contribs(ea, eb, [&](const uint2 &c) {
+                        const int ci = cell_of(c);
+                        const float w = __uint_as_float(c.y), term = (w * w) * klow(Wc, ci);
+                        unsigned q = (unsigned)(term * du_scale);
+                        if (q == 0u && term > 0.0f) q = 1u;
+                        const unsigned x = (c.x >> 7) & 255u, v = c.x & 127u;
+                        const bool xok = KIND == 0 || x < (unsigned)C;
+                        atomicAdd(&Du[v * C + (KIND == 0 || !xok ? 0u : x)], xok ? q : 0u);
                     });
-                    barrier_keep_vm();
+                    __syncthreads();
                     MF_STAMP(5)
-                    for (int i = tid; i < used * 2; i += NT) cells[i] = 0ull;     // the window's cells
+                    for (int i = tid; i < used; i += NT) Wc[i] = 0ull;          // the window's cells
                     first = false;
                 }
                 f0 = f1;
                 if (f0 < nf) __syncthreads();               // the next window's scan writes the cell bases
             }
-            if (tid < TV) vox[tid].mask = 0ull;
+            if (tid < TV) { vm[tid] = 0u; vm[256 + tid] = 0u; }
             if (F + 64 < G) __syncthreads();                // the next frames' mask pass ORs into cleared masks
         }
         // ---- final pass
-        if (!CELLS_EARLY) issue_loads();
+        // What was requested at the tile's start is taken in HERE, before this tile's stores are issued: the vector-memory
+        // counter retires in order, so behind the stores the wait for these loads would be a wait for the stores' round trip too.
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const int r = wave + q * NW;
+        for (int j = 0; j < CELLS_CR; ++j) asm volatile("" :: "v"(cache_n[j].x), "v"(cache_n[j].y));
 #pragma unroll
-            for (int f = 0; f < F4; ++f) {
-                const unsigned i4 = lane + 64 * f;
-                if (grow[q] && i4 < row4) {
-                    const unsigned i = i4 << 2;                                   // float index inside the row
-                    const unsigned v0 = div_magic(i, P.magicC), rem = i - v0 * C;
-                    unsigned vv[4];
-                    vv[0] = v0;
-                    if (C >= 4) { vv[1] = v0 + (rem + 1 >= (unsigned)C); vv[2] = v0 + (rem + 2 >= (unsigned)C); vv[3] = v0 + (rem + 3 >= (unsigned)C); }
-                    else { vv[1] = div_magic(i + 1, P.magicC); vv[2] = div_magic(i + 2, P.magicC); vv[3] = div_magic(i + 3, P.magicC); }
-                    unsigned *d = Du + (unsigned)r * row_len + i;
-                    const uint4 dq = *reinterpret_cast<const uint4 *>(d);
-                    const unsigned dd[4] = {dq.x, dq.y, dq.z, dq.w};
+        for (int i = 0; i < F4; ++i) {
+            if ((unsigned)(i * NT) < n4) {                  // (uniform)
+                // (the empty asm hides that the slot's fields are the same for every tile: worked out before the loop, they
+                // would be held - and spilled - across it)
+                unsigned pki = pk[i];
+                asm volatile("" : "+v"(pki));
+                if ((pki >> 14) & 1u) {
+                    unsigned j = tid + 256u * i;
+                    asm volatile("" : "+v"(j));
+                    const uint4 dq = *reinterpret_cast<const uint4 *>(Du + 4u * j);
+                    *reinterpret_cast<uint4 *>(Du + 4u * j) = make_uint4(0u, 0u, 0u, 0u);
+                    const unsigned sv0 = pki & 127u, cross = (pki >> 7) & 7u;
+                    float ak[4];
+                    if (C >= 4) {                           // (uniform) a float4 spans two voxels at most
+                        const float a0 = atot[sv0], a1 = atot[(sv0 + 1u) & 127u];
+                        ak[0] = a0; ak[1] = cross > 1u ? a0 : a1; ak[2] = cross > 2u ? a0 : a1; ak[3] = cross > 3u ? a0 : a1;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        oldv[q][f][k] = oldv[q][f][k] * vox[(r << S2) + vv[k]].atot + (float)dd[k] * du_inv;
-                    *reinterpret_cast<uint4 *>(d) = make_uint4(0u, 0u, 0u, 0u);
+                        for (int k = 0; k < 4; ++k) ak[k] = atot[div_magic(4u * j + k, P.magicC) & 127u];
+                    }
+                    const bool changed = (dq.x | dq.y | dq.z | dq.w) != 0u || ak[0] != 1.0f || ak[3] != 1.0f || (C < 4 && (ak[1] != 1.0f || ak[2] != 1.0f));
+                    if (((rows_in >> i) & 1u) && changed) {
+                        const v2f d01 = (v2f){(float)dq.x, (float)dq.y} * (v2f){du_inv, du_inv};
+                        const v2f d23 = (v2f){(float)dq.z, (float)dq.w} * (v2f){du_inv, du_inv};
+                        const v2f o01 = __builtin_elementwise_fma((v2f){oldv[i][0], oldv[i][1]}, (v2f){ak[0], ak[1]}, d01);
+                        const v2f o23 = __builtin_elementwise_fma((v2f){oldv[i][2], oldv[i][3]}, (v2f){ak[2], ak[3]}, d23);
+                        *reinterpret_cast<v4f *>(const_cast<char *>(tile_base) + (size_t)row_offset(pki)) = (v4f){o01[0], o01[1], o23[0], o23[1]};
+                    }
                 }
             }
+            if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two slots at a time (registers: the rows of all seven are held)
         }
-        // Look-ups of the tiles ahead: every load of this wave has landed (the rows were just used), so what was issued one
-        // tile ago costs no wait here (vmcnt retires in order), and what is issued now has a whole tile to come back.
-        issue_lookups();
-        if (tid < 64) {
-            if (tid <= 1) misc[M_OFF + tid] = tn_a * (1 - tid) + tn_b * tid;       // the next tile becomes this one,
-            if (tid == 0) misc[M_NEXT] = nx_tile;                                    // the one after it is published,
-            if (tid <= 1) misc[M_OFFN + tid] = nx_off;                               // the registers move up
-            nx_tile = rng_tile; nx_off = rng_off;
-            rng_tile = p_rng_tile; rng_off = p_rng_off;
-            act_pend = p_act;
-        }
-        // the next tile's first records (landed with the rows) go to this thread's LDS slots: pass 3 is over
-        if (tile_n >= 0) {
-            recbuf[tid] = pre0;
-            if (CEB == 2) recbuf[tid + NT] = pre1;
-        }
-        if (STAMPS && tid == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); stamp_acc[7] += _t - t_last; t_last = _t; }
-#pragma unroll
-        for (int q = 0; q < RPW; ++q)
-#pragma unroll
-            for (int f = 0; f < F4; ++f) {
-                const unsigned i4 = lane + 64 * f;
-                if (grow[q] && i4 < row4) reinterpret_cast<v4f *>(grow[q])[i4] = oldv[q][f];
-            }
         MF_STAMP(6)
-        if (STAMPS && tid == 0) {
-            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_tile;
-            const int nrec = t_b - t_a;
-            atomicMax(&g_stamps[8], dt);
-            const int cls = nrec > 2048 ? 0 : nrec > 512 ? 1 : 2;
-            atomicAdd(&g_stamps[9 + 2 * cls], dt);
-            atomicAdd(&g_stamps[10 + 2 * cls], 1ull);
-        }
         if (tile_n < 0) break;
-        tile = tile_n;
-        barrier_keep_vm();                                   // rows combined, deltas / cells / masks clear, look-up words in place
+#pragma unroll
+        for (int j = 0; j < CELLS_CR; ++j) cache[j] = cache_n[j];
+        item = item_n; item_n = uniform(item_n2); lp += nb;
+        __syncthreads();                                     // rows combined, deltas / cells / masks clear
     }
     if (STAMPS && tid == 0) {
         unsigned long long tot = 0;
         for (int i = 0; i < 8; ++i) { atomicAdd(&g_stamps[i], stamp_acc[i]); tot += stamp_acc[i]; }
         atomicMax(&g_stamps[15], tot);                  // the slowest workgroup
-    }
-}
-
-// ----------------------------------------------------------------------------
-// fuse_wave_kernel: the light and medium tiles of a sparse batch, one wave (or one team of four) per tile
-// ----------------------------------------------------------------------------
-// Of the ~100 k tiles a batch of unrelated frames lists, five in six hold at most 512 records (median 136), yet in
-// fuse_cells_kernel each costs a workgroup seven barrier-delimited phases with one or two of its four waves busy, and
-// the 27 KB of deltas per tile hold the CU at twelve waves.  The SIMDs of both kernels are busy issuing instructions
-// ~90 % of the time (SQ_ACTIVE_INST_ANY, profiles/r04_*): what counts is instructions per tile and per record.  Here a
-// TEAM (one wave for tiles of <= 64 RPL records, four waves = one workgroup for tiles of <= 256 RPL) takes a tile:
-//   * the tile's records are decoded ONCE into registers (4 per record: packed coordinates, class id and frame; the three
-//     ratios) and stay there for every pass;
-//   * the mask pass and the scan cover the whole tile; everything after them runs four times, once per SLAB: the 32
-//     voxels whose first two coordinates have parities (p0, p1).  A record's footprint is 2 x 2 x 2, so exactly one
-//     of its four (corner 0, corner 1) pairs falls into a slab: every sweep handles two corners of every record
-//     (the same corner work in all as one sweep over eight), but needs only 32 x C deltas (6.9 KB at C = 54), a quarter
-//     of the cells and a quarter of the rows in registers - 18 KB of LDS per wave, eight waves per CU, and for a one-wave
-//     team no workgroup barrier anywhere (the LDS unit takes one wave's operations in order);
-//   * a slab's four rows are requested at the start of its sweep and combined at its end (old * prod a + D, two floats
-//     per instruction); a float4 whose voxels received nothing is not written back;
-//   * the work items carry first record, count and origin (tile_list_kernel), the next item is fetched a tile ahead
-//     and one word of each of its records is touched, teams take items round-robin (no tickets).
-// All LDS updates are branch-free: a corner outside the tile ORs / adds into a spare word behind the arrays.
-// A tile the team cannot take - a slab needs more cells than fit, or a record's footprint is clamped at the map
-// border (its two corners of an axis are the same voxel: the parity argument fails) - is appended to the last load
-// class of fuse_cells_kernel's list before anything of it is written; that kernel runs behind this one.
-// Arithmetic is fuse_cells_kernel's: integer sums, suffix form, 31-bit deltas.
-constexpr int WAVE_NT = 256;              // four independent waves, or one team of four
-#ifndef WAVE_RPL_DEF
-#define WAVE_RPL_DEF 8
-#endif
-constexpr int WAVE_RPL = WAVE_RPL_DEF;    // records per thread: tiles of up to 512 (one wave) / 2,048 (four waves) records
-constexpr int WAVE_CW1 = 512, WAVE_CW4 = 1152;    // (voxel, frame) cells of a slab that fit: one-wave team, four-wave team
-constexpr int WAVE_SPARE = 64;            // spare words behind each array (targets of the corners outside the tile)
-
-static __host__ __device__ inline size_t wave_lds_bytes(int C, int team)
-{
-    const size_t cw = team == 1 ? WAVE_CW1 : WAVE_CW4;
-    // masks + cell bases (+ spare), prod a, slab totals + flags, cells (W, S2; + spare), deltas (+ spare)
-    return (512 + WAVE_SPARE) * 4 + 128 + 64 + (cw + WAVE_SPARE) * 16 + ((size_t)32 * C + 32) * 4;
-}
-
-template <int TEAM>
-__device__ __forceinline__ void team_sync()
-{
-    if (TEAM == 1) {
-        // one wave: the LDS unit executes its operations in issue order; the compiler must keep that order
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-    } else {
-        __syncthreads();
-    }
-}
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <int KIND, int TEAM, int RPL, int F4S>     // F4S: float4s per thread and slab, >= ceil(8 C / (64 TEAM))
-__global__ __launch_bounds__(WAVE_NT, (TEAM == 1 ? 2 : 3)) void fuse_wave_kernel(TileParams P)
-{
-    extern __shared__ float smem[];
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    constexpr int TT = 64 * TEAM, CW = TEAM == 1 ? WAVE_CW1 : WAVE_CW4;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = TEAM == 1 ? lane : (int)threadIdx.x;                         // thread of the team
-    const int C = P.C;
-    if (P.ticket[MODE_SLOT] != MODE_CELLS) return;                             // (uniform) not a sparse batch
-    const int n_items = min(P.ticket[TEAM == 1 ? LIGHT_COUNT : MEDIUM_COUNT], P.n_tiles);
-    const int gw = TEAM == 1 ? blockIdx.x * (WAVE_NT / 64) + wave : (int)blockIdx.x;
-    const int NWV = TEAM == 1 ? gridDim.x * (WAVE_NT / 64) : (int)gridDim.x;
-    if (gw >= n_items) return;                                                 // (per team)
-    const int4 *items = P.light + (TEAM == 1 ? 0 : P.n_tiles);
-
-    char *mine = reinterpret_cast<char *>(smem) + (TEAM == 1 ? (size_t)wave * P.wave_lds : 0);
-    unsigned *vm = reinterpret_cast<unsigned *>(mine);                         // [4][128] frame mask 0..31, cell base, mask 32..63, cell base of frame 32; spare
-    float *atot = reinterpret_cast<float *>(vm + 512 + WAVE_SPARE);            // [32] prod a of the slab's voxels
-    int *misc = reinterpret_cast<int *>(atot + 32);                            // [0..3] cells per slab, [4] refuse
-    unsigned long long *Wc = reinterpret_cast<unsigned long long *>(misc + 16);   // [CW + spare] W, then (g, a), then t_f
-    unsigned long long *Sc = Wc + CW + WAVE_SPARE;                             // [CW + spare] S2
-    unsigned *D = reinterpret_cast<unsigned *>(Sc + CW + WAVE_SPARE);          // [32][C] deltas of the slab, units of 2^-CELLS_FX; 32 spare
-    const unsigned n4 = 8u * (unsigned)C;                                      // float4s of a slab (four rows of 2 C)
-    for (int i = t; i < 512 + WAVE_SPARE; i += TT) vm[i] = 0u;
-    for (int i = t; i < 2 * (CW + WAVE_SPARE); i += TT) Wc[i] = 0ull;
-    for (unsigned i = t; i < 32u * C + 32u; i += TT) D[i] = 0u;
-    if (t < 16) misc[t] = 0;
-
-    const int fx_c = 182 - P.fx_shift;
-    const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
-    const float du_inv = __uint_as_float((unsigned)(127 - CELLS_FX) << 23);
-    const float du_scale = __uint_as_float((unsigned)(127 + CELLS_FX) << 23);
-    const float iw = P.iw;
-    // scan (first wave of the team): the lane owns the voxels 2 lane, 2 lane + 1 of the slab-major order (slab = lane / 16)
-    const int nv0 = ((lane >> 5) + 2 * ((lane >> 3) & 1)) * 32 + (((lane >> 4) & 1) + 2 * ((lane >> 2) & 1)) * 8 + 2 * (lane & 3);
-    // final pass: float4 j = t + TT i of a slab: its byte offset in slab (0, 0) from the tile's first voxel, its first
-    // voxel and how many of its four floats belong to that voxel (tile-invariant)
-    const unsigned rsb = (unsigned)P.size2 * (unsigned)C * 4u;                  // bytes between map rows (x + 1)
-    unsigned pk[F4S], offs[F4S];
-#pragma unroll
-    for (int i = 0; i < F4S; ++i) {
-        const unsigned j = t + (unsigned)TT * i, c2 = 2u * C;
-        const unsigned row = (j >= c2) + (j >= 2 * c2) + (j >= 3 * c2), col4 = j - row * c2;
-        const unsigned e = 4u * col4, svr = div_magic(e, P.magicC), rem = e - svr * C;
-        const unsigned cross = min(4u, (unsigned)C - rem);
-        pk[i] = (row * 8u + svr) | (cross << 5) | (row << 8) | ((j < n4 ? 1u : 0u) << 10);
-        offs[i] = ((2u * (row >> 1)) * (unsigned)P.size1 + 2u * (row & 1u)) * rsb + col4 * 16u;
-    }
-
-    // corner weights of a record's pair in the slab: per axis (projection.py:280-316) r < 0.5: (0.5 - r, r + 0.5), else
-    // (1.5 - r, r - 0.5); (w0 * w1) * w2 + 1e-9 in the reference's order (projection.py:319-323)
-    auto pair_weights = [](float r0, float r1, float r2, int ca, int cb, float &wl, float &wh) {
-        const float w0 = ca ? r0 + (r0 < 0.5f ? 0.5f : -0.5f) : (r0 < 0.5f ? 0.5f : 1.5f) - r0;
-        const float w1 = cb ? r1 + (r1 < 0.5f ? 0.5f : -0.5f) : (r1 < 0.5f ? 0.5f : 1.5f) - r1;
-        const float w01 = w0 * w1;
-        wl = 1e-9f + w01 * ((r2 < 0.5f ? 0.5f : 1.5f) - r2);
-        wh = 1e-9f + w01 * (r2 + (r2 < 0.5f ? 0.5f : -0.5f));
-    };
-    auto load_records = [&](int first, int n, uint4 (&raw)[RPL]) {
-#pragma unroll
-        for (int b = 0; b < RPL; ++b) {
-            raw[b] = make_uint4(0u, 0u, 0u, 0u);
-            if (b * TT < n) {                                                   // (uniform)
-                const int k = b * TT + t;
-                raw[b] = P.rec[first + (k < n ? k : n - 1)];
-            }
-        }
-    };
-    int4 item = items[gw];
-    item.y = __builtin_amdgcn_readfirstlane(item.y); item.z = __builtin_amdgcn_readfirstlane(item.z);
-    uint4 raw[RPL];
-    load_records(item.y, item.z, raw);
-    team_sync<TEAM>();                                                          // the zeroed arrays
-
-    for (int it = gw; it < n_items; it += NWV) {
-        const int tile = __builtin_amdgcn_readfirstlane(item.x), n = __builtin_amdgcn_readfirstlane(item.z), n_tile = n;
-        const unsigned org = (unsigned)__builtin_amdgcn_readfirstlane(item.w);
-        const int o0 = org & 1023u, o1 = (org >> 10) & 1023u, o2 = org >> 20;
-        int4 item_n = make_int4(-1, 0, 0, 0);
-        if (it + NWV < n_items) item_n = items[it + NWV];                      // (uniform) lands while the masks are built
-
-        // ---- decode (once per tile) + mask pass
-        unsigned meta[RPL];                                                     // coordinate + 1 of the lower corner (3 + 3 + 4 bits), class id (8), frame (6)
-        float q0[RPL], q1[RPL], q2[RPL];                                        // the three ratios (the weights are worked out where they are used)
-        bool clamped = false;
-#pragma unroll
-        for (int b = 0; b < RPL; ++b) {
-            meta[b] = 15u << 6;                                                 // no record: its corners lie outside (z = 14, 15)
-            q0[b] = q1[b] = q2[b] = 0.0f;
-            if (b * TT < n) {                                                   // (uniform)
-                const uint4 r = raw[b];
-                const bool live = b * TT + t < n;
-                const unsigned in8 = live ? (r.x & 255u) : 0u;
-                clamped |= live && ((r.x >> 8) & 7u) != 7u;
-                // a corner set that is empty on the lower side of an axis: the lower corner lies one voxel before the tile
-                const bool m0 = (in8 & 0x0fu) == 0u, m1 = (in8 & 0x33u) == 0u, m2 = (in8 & 0x55u) == 0u;
-                const int v000 = (int)((r.x >> 11) & 1023u) - META_VOFF;
-                const int vv = v000 + (m0 ? 32 : 0) + (m1 ? 8 : 0) + (m2 ? 1 : 0);
-                const unsigned a0p = m0 ? 0u : ((unsigned)(vv >> 5) & 3u) + 1u, a1p = m1 ? 0u : ((unsigned)(vv >> 3) & 3u) + 1u,
-                               a2p = m2 ? 0u : ((unsigned)vv & 7u) + 1u;
-                const unsigned f = (unsigned)meta_frame(r) & 63u;
-                if (live) meta[b] = a0p | (a1p << 3) | (a2p << 6) | (meta_label(r) << 10) | (f << 18);
-                q0[b] = __uint_as_float(r.y & 0x3fffffffu); q1[b] = __uint_as_float(r.z & 0x3fffffffu); q2[b] = __uint_as_float(r.w & 0x3fffffffu);
-                // which of these frames touch which voxel (a corner outside the tile ORs into a spare word of its lane:
-                // lanes that share an address are served one by one)
-                const unsigned bit = 1u << (f & 31u);
-                const int hb = (int)(f >> 5) * 256;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int vc = v000 + ((c & 4) ? 32 : 0) + ((c & 2) ? 8 : 0) + (c & 1);
-                    atomicOr(&vm[(in8 >> c) & 1u ? hb + (vc & 127) : 512 + lane], bit);
-                }
-            }
-        }
-        team_sync<TEAM>();
-        // ---- scan: cell bases per slab (the 16 lanes of a slab scan their 32 voxels)
-        if (TEAM == 1 || t < 64) {
-            const unsigned mA0 = vm[nv0], mA1 = vm[nv0 + 1], mB0 = vm[256 + nv0], mB1 = vm[256 + nv0 + 1];
-            const int nl0 = __popc(mA0), nl1 = __popc(mA1), c0n = nl0 + __popc(mB0), c1n = nl1 + __popc(mB1);
-            int inc = c0n + c1n;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { const int y = __shfl_up(inc, o, 16); if ((lane & 15) >= o) inc += y; }
-            const int ex = inc - (c0n + c1n);
-            vm[128 + nv0] = (unsigned)ex; vm[384 + nv0] = (unsigned)(ex + nl0);
-            vm[128 + nv0 + 1] = (unsigned)(ex + c0n); vm[384 + nv0 + 1] = (unsigned)(ex + c0n + nl1);
-            if ((lane & 15) == 15) misc[lane >> 4] = inc;
-        }
-        if (clamped) misc[4] = 1;
-        team_sync<TEAM>();
-        const int most = max(max(misc[0], misc[1]), max(misc[2], misc[3]));
-        const bool refuse = __builtin_amdgcn_readfirstlane(most > CW || misc[4] != 0);       // (uniform)
-        // the next item has landed by now: one word of each of its records is requested here (nothing waits for them), so
-        // that the loads at the end of this tile find the lines in L2
-        item_n.y = __builtin_amdgcn_readfirstlane(item_n.y); item_n.z = __builtin_amdgcn_readfirstlane(item_n.z);
-        unsigned touch = 0u;
-#pragma unroll
-        for (int b = 0; b < RPL; ++b)
-            if (b * TT < item_n.z) touch |= reinterpret_cast<const unsigned *>(P.rec + item_n.y + min(b * TT + t, item_n.z - 1))[0];
-
-        if (refuse) {
-            if (t == 0) {
-                const int pos = atomicAdd(&P.ticket[1 + TILE_CLASSES - 1], 1);
-                P.active_rw[(TILE_CLASSES - 1) * P.n_tiles + pos] = tile;
-                atomicAdd(&P.ticket[WAVE_REFUSED], 1);
-            }
-        } else {
-            const char *tile_base = reinterpret_cast<const char *>(P.map + ((size_t)o0 * P.size1 + o1) * ((size_t)P.size2 * C) + (size_t)o2 * C);
-            // rows of the tile that lie outside the map (a map whose extents are no multiples of four): bit 8 s + i
-            // clear; one word per thread covers four sweeps of up to eight float4s
-            unsigned rows_in = 0xffffffffu;
-            if (o0 + 4 > P.size0 || o1 + 4 > P.size1) {                        // (uniform, rare)
-                rows_in = 0u;
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int i = 0; i < F4S; ++i) {
-                        const unsigned row = (pk[i] >> 8) & 3u;
-                        if (o0 + (s >> 1) + 2 * (int)(row >> 1) < P.size0 && o1 + (s & 1) + 2 * (int)(row & 1u) < P.size1) rows_in |= 1u << (8 * s + i);
-                    }
-            }
-#pragma unroll 1
-            for (int s = 0; s < 4; ++s) {
-                // (loop-invariant uniform conditions - which record slots and float4 slots are in use - would make the compiler
-                // clone the loop body for their combinations, 55 k instructions instead of 5 k: hidden from it)
-                int n = n_tile, C = P.C;
-                unsigned n4 = 8u * (unsigned)C;
-                asm volatile("" : "+s"(n), "+s"(n4), "+s"(C));
-                const int p0 = s >> 1, p1 = s & 1;
-                const int used = __builtin_amdgcn_readfirstlane(misc[s]);      // cells of this slab
-                const unsigned slab_off = ((unsigned)p0 * (unsigned)P.size1 + (unsigned)p1) * rsb;
-                const unsigned ok_s = rows_in >> (8 * s);
-                // ---- the slab's rows, requested now, combined at the end of the sweep
-                v4f oldv[F4S];
-#pragma unroll
-                for (int i = 0; i < F4S; ++i) {
-                    oldv[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                    if ((unsigned)(i * TT) < n4) {                              // (uniform)
-                        unsigned pki = pk[i], ofi = offs[i];
-                        asm volatile("" : "+v"(pki), "+v"(ofi));                // (nothing of them is kept across the sweeps)
-                        if (((pki >> 10) & 1u) && ((ok_s >> i) & 1u)) oldv[i] = *reinterpret_cast<const v4f *>(tile_base + (size_t)(slab_off + ofi));
-                    }
-                }
-                // ---- pass 1: W, S2 of the slab's cells (two corners per record)
-                unsigned ci[RPL], dd[RPL];                                      // the pair's two cells and two delta words (16 bits each), kept for pass 3
-                float sql[RPL], sqh[RPL];                                       // ... and its squared weights
-#pragma unroll
-                for (int b = 0; b < RPL; ++b) {
-                    ci[b] = dd[b] = 0u; sql[b] = sqh[b] = 0.0f;
-                    if (b * TT < n) {                                           // (uniform)
-                        // (the empty asm hides from the compiler that a record's fields are the same in every sweep: it would
-                        // work all of them out before the loop and hold ~20 registers per record across it)
-                        unsigned m = meta[b];
-                        float r0 = q0[b], r1 = q1[b], r2 = q2[b];
-                        asm volatile("" : "+v"(m), "+v"(r0), "+v"(r1), "+v"(r2));
-                        const int a0 = (int)(m & 7u) - 1, a1 = (int)((m >> 3) & 7u) - 1, a2 = (int)((m >> 6) & 15u) - 1;
-                        const int ca = (a0 ^ p0) & 1, cb = (a1 ^ p1) & 1;
-                        const int c0 = a0 + ca, c1 = a1 + cb;
-                        const bool in01 = (unsigned)c0 < 4u && (unsigned)c1 < 4u;
-                        const bool inl = in01 && (unsigned)a2 < 8u, inh = in01 && (unsigned)(a2 + 1) < 8u;
-                        const int vl = (c0 * 32 + c1 * 8 + a2) & 127, vh = (c0 * 32 + c1 * 8 + a2 + 1) & 127;
-                        const unsigned f = (m >> 18) & 63u, below = (1u << (f & 31u)) - 1u;
-                        const unsigned *mw = vm + (f >> 5) * 256u;
-                        const unsigned ml = mw[vl], bl = mw[128 + vl], mh = mw[vh], bh = mw[128 + vh];
-                        int cl = (int)bl + __popc(ml & below), ch = (int)bh + __popc(mh & below);
-                        cl = inl ? cl : CW + lane; ch = inh ? ch : CW + lane;   // outside: a spare cell takes it
-                        float wl, wh;
-                        pair_weights(r0, r1, r2, ca, cb, wl, wh);
-                        const float wl2 = wl * wl, wh2 = wh * wh;
-                        atomicAdd(&Wc[cl], to_fixed(wl, fx_c));
-                        atomicAdd(&Sc[cl], to_fixed(wl2, fx_c));
-                        atomicAdd(&Wc[ch], to_fixed(wh, fx_c));
-                        atomicAdd(&Sc[ch], to_fixed(wh2, fx_c));
-                        // delta words of the pair (pass 3): [32][C] at (slab voxel, class id), a spare word when outside / class id invalid
-                        const unsigned x = (m >> 10) & 255u;
-                        const bool xok = KIND == 0 || x < (unsigned)C;
-                        const int svb = ((c0 >> 1) * 2 + (c1 >> 1)) * 8;
-                        const unsigned dl = inl && xok ? (unsigned)(svb + a2) * C + (KIND == 0 ? 0u : x) : 32u * C + (lane & 31);
-                        const unsigned dh = inh && xok ? (unsigned)(svb + a2 + 1) * C + (KIND == 0 ? 0u : x) : 32u * C + (lane & 31);
-                        ci[b] = (unsigned)cl | ((unsigned)ch << 16);
-                        dd[b] = dl | (dh << 16);
-                        sql[b] = wl2; sqh[b] = wh2;
-                    }
-                    if (b & 1) __builtin_amdgcn_sched_barrier(0);               // two records at a time: the unrolled loop would keep all eight in flight (registers)
-                }
-                team_sync<TEAM>();
-                // ---- pass 2a: per cell g = iw / W, a = 1 - iw S2 / W
-                for (int i = t; i < used; i += TT) {
-                    const float rW = __builtin_amdgcn_rcpf((float)Wc[i] * fx_inv);
-                    float2 ga; ga.x = iw * rW; ga.y = 1.0f - iw * (((float)Sc[i] * fx_inv) * rW);
-                    *reinterpret_cast<float2 *>(Wc + i) = ga;
-                    Sc[i] = 0ull;
-                }
-                team_sync<TEAM>();
-                // ---- pass 2b: per voxel, from the last frame to the first: t_f = g_f prod_{f' > f} a_f'
-                if (t < 32) {
-                    const int v = (p0 + 2 * ((t >> 4) & 1)) * 32 + (p1 + 2 * ((t >> 3) & 1)) * 8 + (t & 7);
-                    const int cs = (int)vm[128 + v], cnt = __popc(vm[v]) + __popc(vm[256 + v]);
-                    float run = 1.0f;
-                    for (int j = cs + cnt - 1; j >= cs; --j) {
-                        const float2 ga = *reinterpret_cast<const float2 *>(Wc + j);
-                        reinterpret_cast<float *>(Wc + j)[0] = ga.x * run;
-                        run *= ga.y;
-                    }
-                    atot[t] = run;
-                }
-                team_sync<TEAM>();
-                // ---- pass 3: D += t_f w^2 (the class-id / ones feature is 1)
-#pragma unroll
-                for (int b = 0; b < RPL; ++b) {
-                    if (b * TT < n) {                                           // (uniform)
-                        const float tl = klow(Wc, (int)(ci[b] & 0xffffu)), th = klow(Wc, (int)(ci[b] >> 16));
-                        const float terml = sql[b] * tl, termh = sqh[b] * th;
-                        unsigned ql = (unsigned)(terml * du_scale), qh = (unsigned)(termh * du_scale);
-                        if (ql == 0u && terml > 0.0f) ql = 1u;                  // "non-zero" survives
-                        if (qh == 0u && termh > 0.0f) qh = 1u;
-                        atomicAdd(&D[dd[b] & 0xffffu], ql);
-                        atomicAdd(&D[dd[b] >> 16], qh);
-                    }
-                    if (b & 1) __builtin_amdgcn_sched_barrier(0);
-                }
-                team_sync<TEAM>();
-                for (int i = t; i < used; i += TT) Wc[i] = 0ull;                // the slab's cells
-                // ---- final pass of the slab: old * prod a + D, two floats per instruction
-#pragma unroll
-                for (int i = 0; i < F4S; ++i) {
-                    if ((unsigned)(i * TT) < n4) {                              // (uniform)
-                        unsigned pki = pk[i], ofi = offs[i];
-                        asm volatile("" : "+v"(pki), "+v"(ofi));
-                        if ((pki >> 10) & 1u) {
-                            const unsigned j = t + (unsigned)TT * i;
-                            const uint4 dq = *reinterpret_cast<const uint4 *>(D + 4u * j);
-                            *reinterpret_cast<uint4 *>(D + 4u * j) = make_uint4(0u, 0u, 0u, 0u);
-                            const unsigned sv0 = pki & 31u, cross = (pki >> 5) & 7u;
-                            float ak[4];
-                            if (C >= 4) {                                       // (uniform) a float4 spans two voxels at most
-                                const float a0 = atot[sv0], a1 = atot[(sv0 + 1u) & 31u];
-                                ak[0] = a0; ak[1] = cross > 1u ? a0 : a1; ak[2] = cross > 2u ? a0 : a1; ak[3] = cross > 3u ? a0 : a1;
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) ak[k] = atot[div_magic(4u * j + k, P.magicC) & 31u];
-                            }
-                            const bool changed = (dq.x | dq.y | dq.z | dq.w) != 0u || ak[0] != 1.0f || ak[3] != 1.0f || (C < 4 && (ak[1] != 1.0f || ak[2] != 1.0f));
-                            if (((ok_s >> i) & 1u) && changed) {
-                                const v2f d01 = (v2f){(float)dq.x, (float)dq.y} * (v2f){du_inv, du_inv};
-                                const v2f d23 = (v2f){(float)dq.z, (float)dq.w} * (v2f){du_inv, du_inv};
-                                const v2f o01 = __builtin_elementwise_fma((v2f){oldv[i][0], oldv[i][1]}, (v2f){ak[0], ak[1]}, d01);
-                                const v2f o23 = __builtin_elementwise_fma((v2f){oldv[i][2], oldv[i][3]}, (v2f){ak[2], ak[3]}, d23);
-                                *reinterpret_cast<v4f *>(const_cast<char *>(tile_base) + (size_t)(slab_off + ofi)) = (v4f){o01[0], o01[1], o23[0], o23[1]};
-                            }
-                        }
-                    }
-                    if (i & 1) __builtin_amdgcn_sched_barrier(0);
-                }
-                team_sync<TEAM>();
-            }
-        }
-        // the masks of this tile, the refuse flag
-        if (TEAM == 1 || t < 64) { vm[nv0] = 0u; vm[nv0 + 1] = 0u; vm[256 + nv0] = 0u; vm[256 + nv0 + 1] = 0u; }
-        if (t == 0) misc[4] = 0;
-        team_sync<TEAM>();
-        item = item_n;
-        asm volatile("" :: "v"(touch));                                         // (keeps the touching loads)
-        load_records(item.y, item.z, raw);
+        atomicAdd(&g_stamps[14], tot);
     }
 }
 
@@ -2981,22 +2594,22 @@ static bool dense_shape_ok(const mf_grid *g, int G)
            ((size_t)g->channels << DENSE_SV) / 4 <= 4 * 512;
 }
 
-// fuse_cells_kernel: per voxel 16 bytes (mask, cell base, prod a), cap + 1 cells of 16 bytes, 4-byte deltas, look-up words
+// fuse_cells_kernel: per voxel 16 bytes of masks and cell bases, prod a, look-up words, cap + 1 cells of 16 bytes, 4-byte deltas
 constexpr int CELLS_SV = 7, CELLS_NT = 256;          // 4 x 4 x 8 tiles, 256 threads (the instantiation the host launches)
 static size_t cells_lds_bytes(int C, int cap)
 {
     const size_t TV = (size_t)1 << CELLS_SV;
-    return (TV + 1) * 16 + (size_t)(cap + 1) * 16 + (size_t)CELLS_RB * (CELLS_NT / 256) * 32 + TV * C * 4 + CELLS_MISC * 4;
+    return TV * 16 + TV * 4 + 128 * 4 + (size_t)(cap + 1) * 16 + TV * C * 4;
 }
 
 // Workgroups of fuse_cells_kernel per CU and the cells each of them holds: as many workgroups as leave each at
 // least 1,100 cells (a tile of a batch of unrelated frames needs ~600), eight at most (256 threads each).
-static bool cells_config(int C, int lds_per_cu, int reserve, int &cap, int &per_cu)
+static bool cells_config(int C, int lds_per_cu, int reserve, int most, int &cap, int &per_cu)
 {
     static const int forced = env_int("MF_CELLS_PER_CU", 1, 8, 0);            // dev
-    if (C > 64) return false;                                                  // a tile row in two float4s per lane
+    if (C > 64) return false;                                                  // the tile image in eight float4s per thread
     const size_t fixed = cells_lds_bytes(C, 0);
-    for (per_cu = forced > 0 ? forced : 8; per_cu >= 1; --per_cu) {
+    for (per_cu = forced > 0 ? forced : most; per_cu >= 1; --per_cu) {
         const size_t budget = ((size_t)(lds_per_cu - reserve) / per_cu) & ~(size_t)2047;   // LDS is handed out in blocks (three requests of 53 KB did not share a CU, three of 52 KB do)
         const size_t want = forced > 0 || per_cu == 1 ? (size_t)((1 << CELLS_SV) + 1) * 16 : (size_t)800 * 16;
         if (budget < fixed + want) { if (forced > 0) return false; continue; }
@@ -3134,7 +2747,7 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
     size_t off = 0;
     L.cursor = off; off = align_up(off + (size_t)(n_keys + 1) * 4, 256);
     L.block_sums = off; off = align_up(off + (size_t)L.n_scan_blocks * 4, 256);
-    L.ticket = off; off = align_up(off + 256, 256);
+    L.ticket = off; off = align_up(off + 512, 256);
     // split-tile scratch (zeroed with the counters): a tile qualifies with > SPLIT_MIN of the <= cap records
     L.split_slots = L.split_items = 0;
     // the single-pass path is for frame-sized calls; a large merged batch is the tile kernel's throughput regime
@@ -3152,7 +2765,7 @@ static bool make_layout(const mf_grid *g, long long n_points, int G, int s0, int
         L.slot_count = L.slot_ws = L.slot_u = L.slot_bits = off;
     }
     L.active = off; off = align_up(off + (size_t)(n_keys / G) * TILE_CLASSES * 4, 256);
-    L.light = off; off = align_up(off + (size_t)(n_keys / G) * 2 * 16, 256);      // work items of fuse_wave_kernel (two lists)
+    L.light = off; off = align_up(off + (G >= 2 ? (size_t)(n_keys / G) * CELL_CLASSES * 16 : 0), 256);   // work items of fuse_cells_kernel (sequential calls)
     L.items = off; off = align_up(off + (size_t)L.split_items * 8, 256);
     L.rec = off; off = align_up(off + (size_t)cap * 16, 256);
     L.aux = off; off = align_up(off + (size_t)cap * 4, 256);
@@ -3292,8 +2905,10 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     // the LDS budget of fuse_tiles_kernel; a function of the arguments only (a commit on its own agrees with its
     // staging call, a repeated run with itself)
     const bool dense_tiles = FRONT == 0 && P.G >= 2 && int_tiles_ok(grid, P.G, P.feat_kind, P.iw);
-    P.meta = dense_tiles ? 1 : 0;        // tile-local records: the all-integer kernels take every call bucketed on their tiles
     choose_tile(grid, P.G, dense_tiles, P.s0, P.s1, P.s2);
+    // tile-local entries (contributions): only the all-integer kernels read them, and they take every call bucketed on
+    // their 4 x 4 x 8 tiles (an MF_TILE override of the shape keeps the point records that fuse_tiles_kernel reads)
+    P.meta = dense_tiles && P.s0 == 2 && P.s1 == 2 && P.s2 == 3 ? 1 : 0;
     Layout L;
     if (!make_layout(grid, P.n_points, P.G, P.s0, P.s1, P.s2, L, P.nt0, P.nt1, P.nt2))
         return fail(MF_ERR_INVALID, "problem too large for 32-bit bucket offsets (points %lld, groups %d)",
@@ -3360,6 +2975,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     const bool merged_batch = FRONT == 0 && P.G == 1 && P.n_frames >= dense_min_frames;
     const bool use_dense = (dense_tiles || merged_batch) && sv == DENSE_SV && P.s2 == 3 && P.feat_kind != MF_FEAT_DENSE_F32 && P.vec4 &&
                        dlds <= (size_t)dev.lds_per_cu && (P.G + dgc - 1) / dgc <= DENSE_MAX_CHUNKS;
+    if (P.meta && !use_dense) return fail(MF_ERR_INVALID, "internal: contributions were chosen for a call no integer tile kernel takes");
     const int dnt = dense_nt >= 1024 ? 1024 : 512;
     int dper = (int)((size_t)dev.lds_per_cu / dlds);
     if (dper > 2048 / dnt) dper = 2048 / dnt;
@@ -3374,19 +2990,13 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     int cells_cap = 0, cells_per_cu = 1;
     const bool use_cells = cells_on && dense_tiles && use_dense && sv == CELLS_SV && P.s2 == 3 && P.s0 == 2 && P.G >= 2 &&
                            // (a commit on its own runs beside the bucketing kernels of the next batch: they need a few KB of LDS per CU)
-                           cells_config(P.C, dev.lds_per_cu, phase == 3 ? 0 : 8192, cells_cap, cells_per_cu);
+                           // ... and wave slots / registers: two workgroups per CU beside them (headline, pipelined: 24.5 k frames/s
+                           // against 20.3 k with three), three when the call has the chip to itself (equal alone: 1.84 / 1.89 ms)
+                           cells_config(P.C, dev.lds_per_cu, phase == 3 ? 0 : 8192, phase == 3 ? 3 : 2, cells_cap, cells_per_cu);
     int blocks_cells = dev.cus * cells_per_cu;
     if (blocks_cap > 0 && blocks_cells > blocks_cap) blocks_cells = blocks_cap;
     if (blocks_cells > P.n_tiles) blocks_cells = P.n_tiles;
 
-    // the light and medium tiles of such a batch go to fuse_wave_kernel, one wave / one workgroup each (MF_WAVE_MAX /
-    // MF_TEAM_MAX: records up to which a tile counts as light / medium, 0 keeps the kernel out; dev / tests)
-    static const int wave_max = env_int("MF_WAVE_MAX", 0, 64 * WAVE_RPL, 0);
-    static const int team_max = env_int("MF_TEAM_MAX", 0, 256 * WAVE_RPL, 0);
-    const size_t wlds1 = wave_lds_bytes(P.C, 1) * (WAVE_NT / 64), wlds4 = wave_lds_bytes(P.C, 4);
-    const bool wave_ok = use_cells && P.G <= 64 && P.C <= 64;
-    const bool use_wave = wave_ok && wave_max > 0 && 2 * wlds1 <= (size_t)dev.lds_per_cu;
-    const bool use_team = wave_ok && team_max > 0 && 3 * wlds4 <= (size_t)dev.lds_per_cu;
     const int list_dense_tv = (use_dense || use_cells ? 1 << sv : 0) | (use_dense ? 1 << 20 : 0) | (use_cells ? 1 << 21 : 0) |
                               (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0) |
                               (P.meta ? 1 << 24 : 0);
@@ -3399,7 +3009,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     LM.min_mean = P.feat_kind == MF_FEAT_ONES || mc ? 0 : single_min_mean;
     LM.first_ticket = 4 * blocks; LM.dense_tv = list_dense_tv; LM.first_ticket_dense = 4 * blocks_dense; LM.first_ticket_cells = blocks_cells;
     LM.abort = follower ? mc->abort : P.ticket + ABORT_SLOT;
-    LM.light_max = use_wave ? wave_max : 0; LM.medium_max = use_team ? team_max : 0; LM.light = (int4 *)(ws + L.light);
+    LM.items4 = (int4 *)(ws + L.light);
     if (mc && mc->role == 2) { *mc->plan = LM; return MF_OK; }
     if (follower) {
         // the first map's kernels have zeroed this map's counters and split scratch, found its feature range and
@@ -3428,7 +3038,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     {
         ListParams LP;
         LP.cursor = P.cursor; LP.n_tiles = P.n_tiles; LP.G = P.G; LP.split_part = split_part();
-        LP.nt1 = P.nt1; LP.nt2 = P.nt2; LP.s0 = P.s0; LP.s1 = P.s1; LP.s2 = P.s2;
+        LP.nt1 = P.nt1; LP.nt2 = P.nt2; LP.s0 = P.s0; LP.s1 = P.s1; LP.s2 = P.s2; LP.meta = P.meta;
         LP.nonempty = P.ticket + SPLIT_NONEMPTY;
         LP.map[0] = LM;
         const int n_lists = mc && mc->role == 0 ? mc->n_lists : 0;
@@ -3481,7 +3091,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     T.ctr = P.ticket;
     T.cells_cap = cells_cap;
     T.meta = P.meta;
-    T.active_rw = nullptr; T.light = nullptr; T.wave_lds = 0;
+    T.light = nullptr;
     // with ones features every tile of a single-group call goes to the single-pass kernel (tile_list_kernel,
     // min_mean = 0): nothing is listed for the tile kernel, whose launch is skipped
     if (!(single && LM.min_mean == 0)) {
@@ -3517,43 +3127,12 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         hipLaunchKernelGGL(dk, dim3(blocks_dense), dim3(dnt), dlds, st, S);   // returns at once unless tile_list_kernel chose it
         MF_LAUNCH_CHECK("fuse_dense_kernel");
     }
-    // before fuse_cells_kernel: a tile they refuse is appended to that kernel's list
-    for (int team = 4; team >= 1; team -= 3) {          // the four-wave teams first: their tiles are the longer ones
-        if (team == 4 ? !use_team : !use_wave) continue;
-        const int per_team = 64 * team, f4s = (8 * P.C + per_team - 1) / per_team;       // float4s per thread and slab
-        void (*wk)(TileParams);
-        if (team == 1) {
-            if (kind == 0) wk = fuse_wave_kernel<0, 1, WAVE_RPL, 1>;
-            else wk = f4s <= 1 ? fuse_wave_kernel<1, 1, WAVE_RPL, 1> : f4s <= 2 ? fuse_wave_kernel<1, 1, WAVE_RPL, 2>
-                    : f4s <= 4 ? fuse_wave_kernel<1, 1, WAVE_RPL, 4> : fuse_wave_kernel<1, 1, WAVE_RPL, 8>;
-        } else {
-            if (kind == 0) wk = fuse_wave_kernel<0, 4, WAVE_RPL, 1>;
-            else wk = f4s <= 1 ? fuse_wave_kernel<1, 4, WAVE_RPL, 1> : fuse_wave_kernel<1, 4, WAVE_RPL, 2>;
-        }
-        const size_t wl = team == 1 ? wlds1 : wlds4;
-        {
-            static std::mutex mu5;
-            static std::unordered_map<const void *, size_t> granted5;
-            std::lock_guard<std::mutex> lock(mu5);
-            size_t &have = granted5[(const void *)wk];
-            if (have < wl) {
-                MF_HIP_CHECK(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
-                have = wl;
-            }
-        }
-        TileParams S = T;
-        S.active_rw = P.active; S.light = (const int4 *)(ws + L.light); S.wave_lds = (int)wave_lds_bytes(P.C, 1);
-        int wblocks = dev.cus * (team == 1 ? 2 : 3);
-        if (blocks_cap > 0 && wblocks > blocks_cap) wblocks = blocks_cap;
-        hipLaunchKernelGGL(wk, dim3(wblocks), dim3(WAVE_NT), wl, st, S);   // returns at once unless tile_list_kernel chose the cells path
-        MF_LAUNCH_CHECK("fuse_wave_kernel");
-    }
     if (use_cells) {
-        const int f4 = (int)((((size_t)P.C << 3) / 4 + 63) / 64);          // float4s per lane and tile row
+        const int f4 = (32 * P.C + CELLS_NT - 1) / CELLS_NT;                 // float4s per thread and tile
         void (*ck)(TileParams);
-        if (kind == 0) ck = stamps ? fuse_cells_kernel<0, 2, 2, 3, CELLS_NT, 1, true> : fuse_cells_kernel<0, 2, 2, 3, CELLS_NT, 1>;
-        else if (f4 <= 1) ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 1, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 1>;
-        else ck = stamps ? fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 2, true> : fuse_cells_kernel<1, 2, 2, 3, CELLS_NT, 2>;
+        if (kind == 0) ck = fuse_cells_kernel<0, 1>;
+        else ck = f4 <= 1 ? fuse_cells_kernel<1, 1> : f4 <= 2 ? fuse_cells_kernel<1, 2> : f4 <= 4 ? fuse_cells_kernel<1, 4> : f4 <= 7 ? fuse_cells_kernel<1, 7> : fuse_cells_kernel<1, 8>;
+        if (stamps && kind == 1 && f4 == 7) ck = fuse_cells_kernel<1, 7, true>;      // (dev: the headline shape)
         const size_t clds = cells_lds_bytes(P.C, cells_cap);
         {
             static std::mutex mu4;
@@ -3567,6 +3146,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         }
         TileParams S = T;
         S.ctr = P.ticket + TICKET_CELLS;
+        S.light = (const int4 *)(ws + L.light);
         hipLaunchKernelGGL(ck, dim3(blocks_cells), dim3(CELLS_NT), clds, st, S);   // returns at once unless tile_list_kernel chose it
         MF_LAUNCH_CHECK("fuse_cells_kernel");
     }
@@ -3612,13 +3192,10 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         fprintf(stderr, "[MF_STAMPS] blocks=%d nt=%d lds=%zu gc=%d | ticket+offs %.1f%% setup %.1f%% chunk-zero %.1f%% P1 %.1f%% P2 %.1f%% P3 %.1f%% final %.1f%% | total %.3g ticks/block\n",
                 blocks, nt, lds, P.gc, 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot,
                 100 * z[4] / tot, 100 * z[5] / tot, 100 * z[6] / tot, tot / blocks);
-        if (z[15]) {
-            const double totc = tot + (double)z[7];
-            fprintf(stderr, "[MF_STAMPS] cells kernel: %d workgroups, cap %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% mask %.1f%% scan %.1f%% pass1 %.1f%% pass2 %.1f%% pass3 %.1f%% rows-in+combine %.1f%% look-ups+rows-out %.1f%% | longest tile %.3g ticks; tiles >2048 records: %llu, mean %.3g ticks; 513..2048: %llu, %.3g; <=512: %llu, %.3g\n",
-                    blocks_cells, cells_cap, totc / blocks_cells, (double)z[15], 100 * z[0] / totc, 100 * z[1] / totc, 100 * z[2] / totc, 100 * z[3] / totc, 100 * z[4] / totc, 100 * z[5] / totc, 100 * z[7] / totc, 100 * z[6] / totc,
-                    (double)z[8], z[10], z[10] ? (double)z[9] / z[10] : 0.0, z[12], z[12] ? (double)z[11] / z[12] : 0.0, z[14], z[14] ? (double)z[13] / z[14] : 0.0);
-        }
-        if (z[7] && !z[15]) fprintf(stderr, "[MF_STAMPS] dense kernel: %d workgroups, gc %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% barrier %.1f%% pass1 %.1f%% look-ups+barrier %.1f%% fetch issue %.1f%% pass2 %.1f%% pass3 %.1f%%\n", blocks_dense, dgc,
+        if (z[15]) fprintf(stderr, "[MF_STAMPS] cells kernel: %d workgroups, cap %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% mask %.1f%% scan %.1f%% pass1 %.1f%% pass2 %.1f%% pass3 %.1f%% final %.1f%% tile end %.1f%%\n",
+                           blocks_cells, cells_cap, (double)z[14] / blocks_cells, (double)z[15], 100.0 * z[0] / z[14], 100.0 * z[1] / z[14], 100.0 * z[2] / z[14], 100.0 * z[3] / z[14],
+                           100.0 * z[4] / z[14], 100.0 * z[5] / z[14], 100.0 * z[6] / z[14], 100.0 * z[7] / z[14]);
+        else if (z[7]) fprintf(stderr, "[MF_STAMPS] dense kernel: %d workgroups, gc %d, mean %.3g ticks, slowest %.3g | tile start %.1f%% barrier %.1f%% pass1 %.1f%% look-ups+barrier %.1f%% fetch issue %.1f%% pass2 %.1f%% pass3 %.1f%%\n", blocks_dense, dgc,
                           tot / blocks_dense, (double)z[7], 100 * z[0] / tot, 100 * z[1] / tot, 100 * z[6] / tot, 100 * z[2] / tot, 100 * z[5] / tot, 100 * z[3] / tot, 100 * z[4] / tot);
     }
     return MF_OK;
@@ -3759,8 +3336,14 @@ int mf_fuse_frame_maps(const mf_grid *grids, const mf_frames *frames, const floa
             f.max_depth != f0.max_depth)
             return fail(MF_ERR_INVALID, "frames[%d] differs from frames[0] in more than its features: the maps of one call "
                         "are updated from the same rays, poses and depth", m);
-        for (int k = 0; k < m; ++k)
+        for (int k = 0; k < m; ++k) {
             if (grids[k].map == g.map) return fail(MF_ERR_INVALID, "maps %d and %d are the same buffer", k, m);
+            // (the lead map's kernels zero the other maps' counters while their own run on the lead's: a shared workspace is
+            // silent corruption)
+            const char *wa = (const char *)workspaces[k], *wb = (const char *)workspaces[m];
+            if (wa && wb && wa < wb + workspace_bytes[m] && wb < wa + workspace_bytes[k])
+                return fail(MF_ERR_INVALID, "the workspaces of maps %d and %d overlap: every map of a call needs one of its own", k, m);
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     const int G = mode == MF_MODE_SEQUENTIAL ? frames[0].n_frames : 1;

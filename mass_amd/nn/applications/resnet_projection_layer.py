@@ -53,6 +53,7 @@ class ResNetProjectionLayer(BaseProjectionLayer):
     def update(self, observation: Dict[str, torch.Tensor]):
         """resnet_projection_layer.py:159-213.  Keys: position, yaw, elevation, depth [H, W, 1],
         rgb [H, W, 3] in [0, 1] (or, as an extension, precomputed ``features`` [h, w, C])."""
+        self._adopt_device()            # (built without .cuda(), like agent.py:721-742 builds these layers)
         depth = torch.as_tensor(observation["depth"], dtype=torch.float32, device=self.data.device)
         if "features" in observation:
             features = torch.as_tensor(observation["features"], dtype=torch.float32, device=self.data.device)

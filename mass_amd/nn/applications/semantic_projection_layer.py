@@ -96,6 +96,7 @@ class SemanticProjectionLayer(BaseProjectionLayer):
             raise RuntimeError(self._CLASS_ERROR)
 
     def _update(self, observation, sequential, validate):
+        self._adopt_device()            # (a layer built without .cuda())
         if validate:
             self.check_labels(synchronize=False)         # whatever an earlier (deferred) update has reported by now
         labels = self._labels(observation["semantic"])

@@ -18,7 +18,10 @@ from mass_amd.utils.projection import (project_camera_rays, spherical_to_cartesi
                                        fuse_frames, Workspace)
 
 
-_POSE_CACHE = {}      # last single-frame pose: {"key": (device, x, y, z, yaw, elevation), "pose": device tensor}
+# Last single-frame pose: ONE (key, pose) tuple, key = (device, x, y, z, yaw, elevation), replaced and read as a
+# whole (a list cell holding a tuple: two host threads that update their own layers can never pair one thread's
+# key with the other's pose, which two separate dict entries allowed).
+_POSE_CACHE = [None]
 
 
 def _edges(origin, cells, resolution):
@@ -97,9 +100,9 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         key = None
         if cache and position.shape[0] == 1:
             key = (self.data.device, *position[0].tolist(), float(yaw[0]), float(elevation[0]))
-            hit = _POSE_CACHE.get("key") == key
-            if hit:
-                return _POSE_CACHE["pose"]
+            entry = _POSE_CACHE[0]
+            if entry is not None and entry[0] == key:
+                return entry[1]
         # eye and up vector in one evaluation of the reference's expression (elementwise: the same bits as two)
         n = yaw.shape[0]
         both = spherical_to_cartesian(torch.cat([yaw, yaw]), torch.cat([elevation, elevation + np.pi / 2]))
@@ -107,10 +110,23 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         if pose.shape[0] != 1:          # one frame: the 12 floats travel with the call (mf_frames.poses_on_host); an upload from
             pose = pose.to(self.data.device, non_blocking=True)      # pageable memory would wait for the stream's earlier work
         if key is not None:
-            _POSE_CACHE["key"], _POSE_CACHE["pose"] = key, pose
+            _POSE_CACHE[0] = (key, pose)
         return pose
 
+    def _adopt_device(self):
+        """A layer that was built without ``.cuda()`` moves itself to the current HIP device the first time it is
+        updated.  The reference's agent builds its two ResNetProjectionLayers that way (agent.py:721-742: ``.train()``
+        only - a 384 x 384 x 96 x 256 map is 14.5 GB, more than the GPUs it ran on had to spare) and updates them
+        on the CPU; here the update IS the HIP pipeline and 288 GB of HBM hold such maps, so the drop-in needs no
+        edit of the caller.  Without a HIP device the operators raise, as everywhere in this package."""
+        if self.data.device.type == "cpu" and torch.cuda.is_available():
+            self.to(torch.device("cuda", torch.cuda.current_device()))
+            extractor = getattr(self, "feature_extractor", None)
+            if extractor is not None and hasattr(extractor, "to"):
+                extractor.to(self.data.device)
+
     def _splat(self, position, yaw, elevation, depth, features, sequential=True, label_status=None):
+        self._adopt_device()
         depth = torch.as_tensor(depth, dtype=torch.float32, device=self.data.device)
         self._map_version += 1
         fuse_frames(self.bins_x, self.bins_y, self.bins_z, self.rays,
@@ -122,6 +138,7 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         """Project one posed depth + feature frame onto the map, in place
         (base_projection_layer.py:282-343).  Keys: position [3], yaw, elevation
         (radians), depth [H, W, 1] metres, features [h, w, C] with h | H, w | W."""
+        self._adopt_device()
         features = torch.as_tensor(observation["features"], dtype=self.data.dtype,
                                    device=self.data.device)
         self._splat(observation["position"], observation["yaw"], observation["elevation"],
@@ -132,6 +149,7 @@ class BaseProjectionLayer(torch.nn.Module, ProjectionLayer):
         """Extension: a leading batch of frames in one call.  sequential=True is
         exactly B successive update() calls (what agent.py does frame by frame);
         False is the functional API's merged point set."""
+        self._adopt_device()
         features = observation.get("features")
         if features is not None:
             features = torch.as_tensor(features, device=self.data.device)

@@ -144,5 +144,14 @@ def update_feature_maps(feature_maps: Union[Mapping[str, Any], Sequence[Any]],
         sem = [lay for lay in layers if isinstance(lay, SemanticProjectionLayer)]
         if sem:
             torch.cuda.current_stream(sem[0].data.device).synchronize()
+            # every semantic layer is looked at (and its status word cleared) before anything is raised: a layer left with
+            # its word set would raise a stale error from its NEXT update and drop a valid observation.  Unlike the
+            # reference's loop, which stops at the first bad layer, the other maps of the step have been updated by then.
+            failure = None
             for lay in sem:
-                lay.check_labels(synchronize=False)
+                try:
+                    lay.check_labels(synchronize=False)
+                except RuntimeError as err:
+                    failure = failure or err
+            if failure is not None:
+                raise failure

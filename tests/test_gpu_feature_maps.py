@@ -316,3 +316,41 @@ def test_two_host_threads_each_with_their_own_maps(device):
     for k in range(2):
         for name in sets[k]:
             same(sets[k][name].data, refs[k][name].data, f"thread {k} {name}")
+
+
+def test_two_host_threads_plain_updates_with_different_poses(device):
+    """The pose cache of plain layer.update() (one entry for all layers: the maps of a step share their pose) is read
+    and replaced as ONE tuple: two threads that update their own layers with different poses at the same time each
+    get their own pose - every map equals what a serial run of the same updates gives (with the key and the pose in
+    two separate dict entries, one thread's key could be paired with the other's pose: a silently wrong map)."""
+    import threading
+    H, W, M, C_sem, n = 48, 64, 32, 5, 40
+    sets = [make_layers(device, H, W, M, C_sem) for _ in range(2)]
+    refs = [make_layers(device, H, W, M, C_sem) for _ in range(2)]
+    frs = [frames(n, H, W, C_sem, 3, seed=77 + k) for k in range(2)]
+    obs = [[observation(frs[k], t, device) for t in range(n)] for k in range(2)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream(device)
+            with torch.cuda.stream(stream):
+                for o in obs[k]:
+                    loop_update(sets[k], o)           # plain layer.update() per map: every call goes through the pose cache
+            stream.synchronize()
+        except Exception as exc:                     # noqa: BLE001
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for o in obs[k]:
+            loop_update(refs[k], o)
+    torch.cuda.synchronize()
+    for k in range(2):
+        for name in sets[k]:
+            same(sets[k][name].data, refs[k][name].data, f"thread {k} {name}")
