@@ -93,7 +93,8 @@ struct FuseParams {
     int nt0, nt1, nt2, n_tiles, n_keys;
     int gc;                    // frames per chunk in the tile kernel
     int vec4;                  // final pass may use 16-byte accesses
-    int meta;                  // entries in the tile-local format: one contribution per corner (all-integer tile kernels), no aux words
+    int meta;                  // entries in a tile-local format (all-integer tile kernels, no aux words): contributions or meta records, see use_contributions
+    int fmt_force;             // 0: the probe decides, 1: contributions, 2: records (only one of the two kernels is offered; dev / tests)
     unsigned magicC;           // ceil(2^32 / C) (0 when C == 1)
     // workspace
     int *cursor;               // [n_keys + 1]
@@ -279,6 +280,21 @@ constexpr int HS_BITS = 8;
 constexpr int HS = 1 << HS_BITS;
 constexpr uint32_t EMPTY = 0xffffffffu;
 
+// Entry format of a call bucketed on 4 x 4 x 8 tiles (P.meta): probe_kernel counts, over a sample of pixel patches, the valid
+// points and the distinct tiles their voxels lie in; count_kernel, scatter_kernel and tile_list_kernel all read the two words
+// and agree: a real scene (tens of points of a 16 x 16 patch in one tile) keeps 16-byte point records and goes to
+// fuse_dense_kernel, a batch of unrelated frames (about one point per tile) is expanded into contributions for
+// fuse_cells_kernel.  A function of the call's data alone.
+constexpr int PROBE_POINTS = ABORT_SLOT + 10, PROBE_TILES = ABORT_SLOT + 11;
+constexpr int FORMAT_SLOT = ABORT_SLOT + 12;    // diagnostics: 1 = contributions, 0 = records (tile_list_kernel)
+constexpr int PROBE_DENSE_RATIO = 8;            // points per distinct tile of a patch from which a scene counts as real
+__device__ __forceinline__ bool use_contributions(const int *ticket, int meta, int fmt_force)
+{
+    if (!meta) return false;
+    if (fmt_force) return fmt_force == 1;
+    return ticket[PROBE_POINTS] < PROBE_DENSE_RATIO * ticket[PROBE_TILES];
+}
+
 // The table pays when the keys of a block repeat (neighbouring pixels of a real scene share their tiles: tens of points
 // per key).  A block of unrelated depths brings ~450 distinct keys for 256 slots: once HS_FILL slots are claimed the
 // table is closed - later keys go to the global counters directly without a search (a wave runs a probe loop as long as
@@ -331,6 +347,89 @@ __device__ __forceinline__ uint4 make_record(const Point &pt)
 }
 
 // ----------------------------------------------------------------------------
+// tile-local records ("meta" format) of the all-integer tile kernels
+// ----------------------------------------------------------------------------
+// A record is written per (point, tile) pair anyway, so for the calls that go to fuse_dense_kernel /
+// fuse_cells_kernel (sequential or merged frames of class ids / ones, front end 0) scatter_kernel stores what the
+// tile kernels would otherwise derive again in every pass, in the same 16 bytes and with no separate class-id word:
+//   x  bits  0..7   corner c = 4 ca + 2 cb + cd lies inside the tile (ca / cb / cd pick the upper corner of axis 0 / 1 / 2)
+//      bits  8..10  d0 d1 d2: upper minus lower voxel index per axis (0 where the footprint is clamped at the map border)
+//      bits 11..20  tile-local id of the all-lower corner + META_VOFF (it may lie one voxel before the tile)
+//      bits 21..28  class id (255 = outside [0, C), counts as an all-zero feature row), bits 29..30 frame bits 6..7
+//   y, z, w  the three ratios (in [0, 1]: sign and top exponent bit clear); their two top bits carry frame bits 0..5.
+constexpr int META_VOFF = 128;
+
+struct AxisLocal { int l, d; bool in_lo, in_hi; };
+__device__ __forceinline__ AxisLocal axis_local(const AxisFoot &a, int origin, int shift)
+{
+    AxisLocal x;
+    x.l = a.lo - origin;
+    x.d = a.hi - a.lo;
+    x.in_lo = ((unsigned)x.l >> shift) == 0u;
+    x.in_hi = ((unsigned)(a.hi - origin) >> shift) == 0u;
+    return x;
+}
+
+__device__ __forceinline__ uint4 make_meta_record(const Point &pt, const AxisFoot &a0, const AxisFoot &a1, const AxisFoot &a2,
+                                                  int o0, int o1, int o2, int s0, int s1, int s2, uint32_t label)
+{
+    const AxisLocal x0 = axis_local(a0, o0, s0), x1 = axis_local(a1, o1, s1), x2 = axis_local(a2, o2, s2);
+    const uint32_t in8 = ((x0.in_lo ? 0x0fu : 0u) | (x0.in_hi ? 0xf0u : 0u)) & ((x1.in_lo ? 0x33u : 0u) | (x1.in_hi ? 0xccu : 0u)) &
+                         ((x2.in_lo ? 0x55u : 0u) | (x2.in_hi ? 0xaau : 0u));
+    const int v000 = x0.l * (1 << (s1 + s2)) + x1.l * (1 << s2) + x2.l;
+    const uint32_t g = (uint32_t)pt.group;
+    uint4 r;
+    r.x = in8 | ((uint32_t)x0.d << 8) | ((uint32_t)x1.d << 9) | ((uint32_t)x2.d << 10) | ((uint32_t)(v000 + META_VOFF) << 11) |
+          ((label > 255u ? 255u : label) << 21) | (((g >> 6) & 3u) << 29);
+    r.y = __float_as_uint(pt.r0) | ((g & 3u) << 30);
+    r.z = __float_as_uint(pt.r1) | (((g >> 2) & 3u) << 30);
+    r.w = __float_as_uint(pt.r2) | (((g >> 4) & 3u) << 30);
+    return r;
+}
+
+__device__ __forceinline__ int meta_frame(const uint4 &r)
+{
+    return (int)((r.y >> 30) | ((r.z >> 30) << 2) | ((r.w >> 30) << 4) | (((r.x >> 29) & 3u) << 6));
+}
+__device__ __forceinline__ uint32_t meta_label(const uint4 &r) { return (r.x >> 21) & 255u; }
+
+// What a pass needs of a meta record: tile-local ids and weights of the eight corners (static register picks once
+// the corner loop is unrolled), the inside mask.
+template <int S1, int S2>
+struct MetaCorners {
+    int v[8];
+    float w[8];
+    uint32_t in8;
+    __device__ __forceinline__ explicit MetaCorners(const uint4 &r)
+    {
+        in8 = r.x & 255u;
+        const int v000 = (int)((r.x >> 11) & 1023u) - META_VOFF;
+        const int e0 = (int)((r.x >> 8) & 1u) << (S1 + S2), e1 = (int)((r.x >> 9) & 1u) << S2, e2 = (int)((r.x >> 10) & 1u);
+        v[0] = v000; v[1] = v000 + e2; v[2] = v000 + e1; v[3] = v[2] + e2;
+        v[4] = v000 + e0; v[5] = v[4] + e2; v[6] = v[4] + e1; v[7] = v[6] + e2;
+        const float r0 = __uint_as_float(r.y & 0x3fffffffu), r1 = __uint_as_float(r.z & 0x3fffffffu), r2 = __uint_as_float(r.w & 0x3fffffffu);
+        // per axis (projection.py:280-316): r < 0.5: (0.5 - r, r + 0.5), else (1.5 - r, r - 0.5)
+        const float l0 = (r0 < 0.5f ? 0.5f : 1.5f) - r0, h0 = r0 + (r0 < 0.5f ? 0.5f : -0.5f);
+        const float l1 = (r1 < 0.5f ? 0.5f : 1.5f) - r1, h1 = r1 + (r1 < 0.5f ? 0.5f : -0.5f);
+        const float l2 = (r2 < 0.5f ? 0.5f : 1.5f) - r2, h2 = r2 + (r2 < 0.5f ? 0.5f : -0.5f);
+        // (w0 * w1) * w2 + 1e-9, the reference's product order (projection.py:319-323)
+        const float w00 = l0 * l1, w01 = l0 * h1, w10 = h0 * l1, w11 = h0 * h1;
+        w[0] = 1e-9f + w00 * l2; w[1] = 1e-9f + w00 * h2; w[2] = 1e-9f + w01 * l2; w[3] = 1e-9f + w01 * h2;
+        w[4] = 1e-9f + w10 * l2; w[5] = 1e-9f + w10 * h2; w[6] = 1e-9f + w11 * l2; w[7] = 1e-9f + w11 * h2;
+    }
+};
+
+// body(cc, v, w) for the corners of a meta record that lie inside the tile
+template <int S1, int S2, class F>
+__device__ __forceinline__ void meta_corners_idx(const uint4 &r, F body)
+{
+    const MetaCorners<S1, S2> m(r);
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc)
+        if (m.in8 & (1u << cc)) body(cc, m.v[cc], m.w[cc]);
+}
+
+// ----------------------------------------------------------------------------
 // tile-local entries ("meta" format) of the all-integer tile kernels: CONTRIBUTIONS
 // ----------------------------------------------------------------------------
 // For the calls that go to fuse_dense_kernel / fuse_cells_kernel (sequential or merged frames of class ids / ones,
@@ -344,6 +443,46 @@ __device__ __forceinline__ uint4 make_record(const Point &pt)
 __device__ __forceinline__ uint2 make_contribution(int v, uint32_t label, int frame, float w)
 {
     return make_uint2((uint32_t)v | ((label > 255u ? 255u : label) << 7) | ((uint32_t)frame << 15), __float_as_uint(w));
+}
+
+// The sample behind use_contributions: block (i, f) takes patch i of `n_probe` evenly spread 16 x 16 patches of frame f and
+// counts its valid points and the distinct tiles their voxels lie in (an LDS set).
+__global__ __launch_bounds__(BIN_THREADS) void probe_kernel(FuseParams P, int n_probe)
+{
+    constexpr int PS = 512;
+    __shared__ uint32_t pset[PS];
+    __shared__ int n_valid, n_distinct;
+    for (int s = threadIdx.x; s < PS; s += BIN_THREADS) pset[s] = EMPTY;
+    if (threadIdx.x == 0) { n_valid = 0; n_distinct = 0; }
+    __syncthreads();
+    const int pw = (P.W + PATCH - 1) / PATCH, ph = (P.H + PATCH - 1) / PATCH, np = pw * ph;
+    const int patch = (int)(((long long)blockIdx.x * np + np / 2) / n_probe) % np;
+    const int py = patch / pw, px = patch - py * pw;
+    const int y = py * PATCH + (int)(threadIdx.x / PATCH), x = px * PATCH + (int)(threadIdx.x % PATCH), f = blockIdx.y;
+    if (y < P.H && x < P.W) {
+        const int pix = y * P.W + x;
+        const float d = P.depth[(long long)f * (P.H * P.W) + pix];
+        float pose[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pose[k] = P.pose_inline ? P.pose0[k] : P.poses[f * 12 + k];
+        float q0, q1, q2;
+        rotate_ray(pose + 3, P.cam[pix * 3], P.cam[pix * 3 + 1], P.cam[pix * 3 + 2], q0, q1, q2);
+        const float m0 = q0 * d, m1 = q1 * d, m2 = q2 * d;
+        int kx, ky, kz; float rx, ry, rz;
+        if (bin_point(P.bins, pose[0] + m0, pose[1] + m1, pose[2] + m2, d, P.min_d, P.max_d, kx, ky, kz, rx, ry, rz)) {
+            const uint32_t key = (uint32_t)(((ky >> P.s0) * P.nt1 + (kx >> P.s1)) * P.nt2 + (kz >> P.s2));
+            atomicAdd(&n_valid, 1);
+            uint32_t h = (key * 2654435761u) >> (32 - 9);
+            for (int probe = 0; probe < PS; ++probe) {
+                const uint32_t cur = atomicCAS(&pset[h], EMPTY, key);
+                if (cur == EMPTY) { atomicAdd(&n_distinct, 1); break; }
+                if (cur == key) break;
+                h = (h + 1) & (PS - 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && n_valid > 0) { atomicAdd(&P.ticket[PROBE_POINTS], n_valid); atomicAdd(&P.ticket[PROBE_TILES], n_distinct); }
 }
 
 template <int FRONT>
@@ -383,7 +522,7 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
             // entries of a bucket: one record per (point, tile), or - tile-local "meta" entries - one contribution per corner
             // inside the tile: the eight corners split evenly over the point's tiles (an axis whose two corners straddle a
             // tile face halves the share)
-            const int inc = P.meta ? 8 >> __popc(K.straddle) : 1;
+            const int inc = use_contributions(P.ticket, P.meta, P.fmt_force) ? 8 >> __popc(K.straddle) : 1;
             const bool open = hash_open(&hfill);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -465,7 +604,8 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
     if (ok) {
         point_keys8(P, pt, K);
     }
-    const int inc_k = ok && P.meta ? 8 >> __popc(K.straddle) : 1;
+    const bool contrib = use_contributions(P.ticket, P.meta, P.fmt_force);       // (uniform)
+    const int inc_k = ok && contrib ? 8 >> __popc(K.straddle) : 1;
     if (ok) {
         const bool open = hash_open(&hfill);
 #pragma unroll
@@ -485,8 +625,8 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
             pos[j] = 0;
             if (K.mask & (1u << j)) pos[j] = slot[j] >= 0 ? hcnt[slot[j]] + rank[j] : atomicAdd(&P.cursor[K.key[j]], inc_k);
         }
-        if (P.meta) {
-            // Tile-local entries for the all-integer tile kernels: one CONTRIBUTION per corner, written to the bucket of the
+        if (contrib) {
+            // Tile-local entries for fuse_cells_kernel: one CONTRIBUTION per corner, written to the bucket of the
             // corner's own tile (make_contribution: voxel inside the tile, class id, frame, corner weight).  Corner c = 4 ca +
             // 2 cb + cd belongs to key position c & straddle; inside a (point, tile) share the corners are numbered by
             // their free bits.  A footprint clamped at the map border has two corners on one voxel: both are written,
@@ -522,6 +662,15 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
                     out[base_hi + idx] = hi;
                 }
             }
+        } else if (P.meta) {
+            // tile-local records for fuse_dense_kernel (no separate class-id word)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (K.mask & (1u << j)) {
+                    const int a = j >> 2, b = (j >> 1) & 1, c = j & 1;
+                    P.rec[pos[j]] = make_meta_record(pt, K.a0, K.a1, K.a2, K.t0[a] << P.s0, K.t1[b] << P.s1, K.t2[c] << P.s2,
+                                                     P.s0, P.s1, P.s2, aux);
+                }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -649,7 +798,7 @@ struct ListParams {
     const int *cursor;             // exclusive offsets
     int n_tiles, G, split_part;
     int nt1, nt2, s0, s1, s2;      // tile grid (the origin of a tile rides in fuse_cells_kernel's work item)
-    int meta;                      // the entries are contributions (tile-local format)
+    int meta, fmt_force;           // entry format of the call (use_contributions)
     const int *nonempty;           // buckets with entries (scan_apply_kernel)
     ListMap map[1 + MAX_EXTRA_MAPS];
 };
@@ -666,20 +815,21 @@ __global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
     const int first_ticket_dense = M.first_ticket_dense, first_ticket_cells = M.first_ticket_cells;
     const int *abort = M.abort;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    // Density of the call: records per non-empty (tile, frame) bucket and tile voxel.  Half a record per
-    // voxel and frame or more is a real scene (a batch of unrelated frames has 0.03): the all-integer
-    // tile kernel takes it when the call was bucketed on its tiles (dense_tv = their voxel count, else 0).
-    // (every thread works the choice out: which list a tile goes to depends on it)
-    // (counted in points: a contribution is 2 / 9 of a point's entry in a tile, 8 corners over 1.76 tiles on average)
-    const long long total = LP.meta ? (long long)cursor[n_tiles * G] * 2 / 9 : (long long)cursor[n_tiles * G];
-    const long long half = (long long)*nonempty * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
-    // bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is, bits 22 / 23: forced (dev / tests),
-    // bit 24: the records are tile-local (meta format): only these two kernels read them
+    // Which tile kernel takes the call (every thread works the choice out: which list a tile goes to depends on it).
+    // Calls bucketed on the 4 x 4 x 8 tiles of the all-integer kernels in a tile-local format (LP.meta): the format -
+    // contributions or records, use_contributions - IS the choice.  Other calls that fuse_dense_kernel is offered
+    // (a merged batch of frames: generic records): by the call's density, records per non-empty (tile, frame) bucket
+    // and tile voxel - half a record per voxel and frame or more is a real scene.
+    // dense_tv: low bits the tiles' voxel count, bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is
     const bool dense_ok = dense_tv & (1 << 20), cells_ok = dense_tv & (1 << 21);
-    const bool dense = dense_ok && !(cells_ok && (dense_tv & (1 << 23))) && (total >= half || (dense_tv & (1 << 22)) || ((dense_tv & (1 << 24)) && !cells_ok));
-    const int tile_mode = dense ? MODE_DENSE : cells_ok ? MODE_CELLS : MODE_TILES;
+    const bool contrib = use_contributions(ticket, LP.meta, LP.fmt_force);
+    const long long total = cursor[n_tiles * G];
+    const long long half = (long long)*nonempty * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
+    const bool dense = dense_ok && (LP.meta ? !contrib : (total >= half || (dense_tv & (1 << 22))));
+    const int tile_mode = dense ? MODE_DENSE : contrib && cells_ok ? MODE_CELLS : MODE_TILES;
     if (t == 0) {
         ticket[MODE_SLOT] = tile_mode;
+        ticket[FORMAT_SLOT] = contrib ? 1 : 0;
         ticket[HINT_SLOT] = (int)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
         ticket[HINT_SLOT + 1] = (int)(half > 0x7fffffffLL ? 0x7fffffffLL : half);
         // every tile kernel deals its first items statically (see there) and has a work counter of its own
@@ -729,8 +879,7 @@ __global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
         }
         return;
     }
-    // (tile-local entries are contributions, ~4.5 per point and tile: the load classes keep their meaning in points)
-    const int cls = tile_class(LP.meta ? n >> 2 : n);
+    const int cls = tile_class(n);
     for (int c = 0; c < TILE_CLASSES; ++c) {
         const bool mine = n > 0 && cls == c;
         const unsigned long long m = __ballot(mine);
@@ -1327,9 +1476,6 @@ __global__ __launch_bounds__(MAXT) void fuse_tiles_kernel(TileParams P)
 constexpr int DENSE_SV = 7;               // 4 x 4 x 8 tiles
 constexpr int DENSE_FX = 40;              // fraction bits of the deltas
 constexpr int DENSE_MAX_CHUNKS = 32;
-#ifndef EBX_DEF
-#define EBX_DEF 16
-#endif
 
 // META: the records are in the tile-local meta format (sequential frames; class id and frame in the record, no aux words)
 template <int KIND, int MAXT, bool META, bool STAMPS = false>
@@ -1410,20 +1556,13 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
     int tile = misc[0];
     if (tile < 0) return;
 
-    // META: the tile's entries are 8-byte contributions (one per corner inside the tile: make_contribution), else
-    // 16-byte point records + class-id words
-    typedef typename std::conditional<META, uint2, uint4>::type Rec;
-    // entries a thread of a big tile has in flight per trip: a contribution is one corner's work (a record was eight), so
-    // sixteen of them are requested together (room batch, kernel alone: 2 per trip 2.14 ms, 4: 1.53, 8: 1.38, 16: 1.30)
-    constexpr int EBX = META ? EBX_DEF : EB;
-    const Rec *recs = reinterpret_cast<const Rec *>(P.rec);
-    Rec pre[EB];
+    uint4 pre[EB];
     uint32_t prex[EB];
-    auto prefetch_entries = [&](int ta, int tb, Rec (&q)[EB], uint32_t (&qx)[EB]) {
+    auto prefetch_entries = [&](int ta, int tb, uint4 (&q)[EB], uint32_t (&qx)[EB]) {
 #pragma unroll
         for (int j = 0; j < EB; ++j) {                     // unconditional (clamped) loads: no branch, no wait in between
             const int e = min(ta + tid + j * NT, tb - 1);
-            q[j] = recs[e];
+            q[j] = P.rec[e];
             qx[j] = (KIND == 1 && !META) ? P.aux[e] : 0u;
         }
     };
@@ -1466,20 +1605,15 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
             MF_STAMP(1)
 
             // ---- pass 1: W, S2 of every (voxel, frame) cell of the chunk
-            auto p1_record = [&](const Rec &r) {
-                if constexpr (META) {
-                    unsigned long long *cell = A + (size_t)((int)((r.x >> 15) & 255u) - f_base) * TVP * 2;
-                    const int v = (int)(r.x & 127u);
-                    const float w = __uint_as_float(r.y);
+            auto p1_record = [&](const uint4 &r) {
+                const int f = (META ? meta_frame(r) : rec_group(r)) - f_base;
+                unsigned long long *cell = A + (size_t)f * TVP * 2;
+                auto add = [&](int, int v, float w) {
                     atomicAdd(&cell[2 * v], to_fixed(w, fx_c));
                     atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
-                } else {
-                    unsigned long long *cell = A + (size_t)(rec_group(r) - f_base) * TVP * 2;
-                    for_corners_idx(P, r, o0, o1, o2, [&](int, int v, float w) {
-                        atomicAdd(&cell[2 * v], to_fixed(w, fx_c));
-                        atomicAdd(&cell[2 * v + 1], to_fixed(w * w, fx_c));
-                    });
-                }
+                };
+                if (META) meta_corners_idx<2, 3>(r, add);
+                else for_corners_idx(P, r, o0, o1, o2, add);
             };
             // A small tile (all its records fit the registers fetched a tile ahead) is taken from there, in
             // straight-line code.  A big tile is dealt in SEGMENTS: thread t walks records [t * S, (t + 1) * S) of
@@ -1499,12 +1633,12 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
                     if (e >= ea && e < eb) p1_record(pre[j]);
                 }
             } else {
-                for (int e = my0; e < my1; e += EBX) {
-                    Rec r[EBX];
+                for (int e = my0; e < my1; e += EB) {
+                    uint4 r[EB];
 #pragma unroll
-                    for (int j = 0; j < EBX; ++j) r[j] = recs[min(e + j, my1 - 1)];
+                    for (int j = 0; j < EB; ++j) r[j] = P.rec[min(e + j, my1 - 1)];
 #pragma unroll
-                    for (int j = 0; j < EBX; ++j)
+                    for (int j = 0; j < EB; ++j)
                         if (e + j < my1) p1_record(r[j]);
                 }
             }
@@ -1580,21 +1714,14 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
             // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1): the t_f of a record's corners are
             // read together (a corner outside the tile reads that of one inside), then integer atomics
             {
-                auto p3_record = [&](const Rec &r, uint32_t x) {
-                    if constexpr (META) {
-                        const unsigned long long *cell = A + (size_t)((int)((r.x >> 15) & 255u) - f_base) * TVP * 2;
-                        const int v = (int)(r.x & 127u);
-                        const float w = __uint_as_float(r.y), term = (w * w) * klow(cell, 2 * v);
-                        unsigned long long m = to_fixed(term, 182 - DENSE_FX);
-                        if (m == 0ull && term > 0.0f) m = 1ull;
-                        if (m != 0ull) atomicAdd(&Di[KIND == 0 ? v : v * C + (int)x], m);
-                    } else {
-                    const unsigned long long *cell = A + (size_t)(rec_group(r) - f_base) * TVP * 2;
+                auto p3_record = [&](const uint4 &r, uint32_t x) {
+                    const unsigned long long *cell = A + (size_t)((META ? meta_frame(r) : rec_group(r)) - f_base) * TVP * 2;
                     int vi[8];
                     float qv[8];
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) vi[cc] = -1;
-                    for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+                    if (META) meta_corners_idx<2, 3>(r, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
+                    else for_corners_idx(P, r, o0, o1, o2, [&](int cc, int v, float w) { vi[cc] = v; qv[cc] = w * w; });
                     int vf = 0;
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) vf = vi[cc] >= 0 ? vi[cc] : vf;
@@ -1608,27 +1735,26 @@ __global__ __launch_bounds__(MAXT, 4) void fuse_dense_kernel(TileParams P)      
                             if (m == 0ull && term > 0.0f) m = 1ull;
                             if (m != 0ull) atomicAdd(&Di[KIND == 0 ? vi[cc] : vi[cc] * C + (int)x], m);
                         }
-                    }
                 };
                 if (!big) {
 #pragma unroll
                     for (int j = 0; j < EB; ++j) {
                         const int e = t_s + tid + j * NT;
-                        const uint32_t x = META ? (pre[j].x >> 7) & 255u : prex[j];
+                        const uint32_t x = META ? meta_label(pre[j]) : prex[j];
                         if (e >= ea && e < eb && (KIND == 0 || x < (uint32_t)C)) p3_record(pre[j], x);
                     }
                 } else {
-                    for (int e = my0; e < my1; e += EBX) {
-                        Rec r[EBX];
-                        uint32_t x[EBX];
+                    for (int e = my0; e < my1; e += EB) {
+                        uint4 r[EB];
+                        uint32_t x[EB];
 #pragma unroll
-                        for (int j = 0; j < EBX; ++j) {
+                        for (int j = 0; j < EB; ++j) {
                             const int q = min(e + j, my1 - 1);
-                            r[j] = recs[q];
-                            x[j] = KIND != 1 ? 0u : META ? (r[j].x >> 7) & 255u : P.aux[q];
+                            r[j] = P.rec[q];
+                            x[j] = KIND != 1 ? 0u : META ? meta_label(r[j]) : P.aux[q];
                         }
 #pragma unroll
-                        for (int j = 0; j < EBX; ++j)
+                        for (int j = 0; j < EB; ++j)
                             if (e + j < my1 && (KIND == 0 || x[j] < (uint32_t)C)) p3_record(r[j], x[j]);
                     }
                 }
@@ -1725,6 +1851,13 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 
 constexpr int CELLS_FX = 31;              // fraction bits of the deltas
 constexpr int CELLS_CR = 4;               // contributions per thread kept in registers (fetched a tile ahead)
+
+// A 64-bit fixed-point sum as a float: two 32-bit conversions and one multiply-add (the compiler's correctly rounded
+// u64 -> f32 is a dozen instructions; the double rounding here is far below the 1e-4 the map is held to).
+__device__ __forceinline__ float u64_to_float(unsigned long long x)
+{
+    return __builtin_fmaf((float)(unsigned)(x >> 32), 4294967296.0f, (float)(unsigned)x);
+}
 
 template <int KIND, int F4, bool STAMPS = false>   // F4: float4s per thread and tile (ceil(32 C / 256))
 __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
@@ -1866,6 +1999,7 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
         load_rows(tile_base, rows_in, true, oldv);
         // the contributions [ea, eb) of this tile: the cached ones from registers, the rest of a heavy tile from
         // memory (one trip ahead, so that the round trip runs beside the body)
+        int cell_kept[CELLS_CR];                                                // pass 1's cells of the cached contributions, for pass 3
         auto for_contribs = [&](int ea, int eb, auto body) {
 #pragma unroll
             for (int j = 0; j < CELLS_CR; ++j) {
@@ -1875,7 +2009,7 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                     // four once and hold the fields in registers across the tile)
                     uint2 c = cache[j];
                     asm volatile("" : "+v"(c.x), "+v"(c.y));
-                    if (k >= ea && k < eb) body(c);
+                    if (k >= ea && k < eb) body(c, cell_kept[j]);
                 }
             }
             // (four loads per thread in flight, one trip ahead: with one, every trip of 256 contributions waited a whole
@@ -1896,8 +2030,10 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                         for (int q = 0; q < 4; ++q) nx[q] = rec2[min(k + NT * (4 + q), eb - 1)];
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (k + NT * q < eb) body(c[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        int none = -1;                                          // (a streamed contribution's cell is worked out in both passes)
+                        if (k + NT * q < eb) body(c[q], none);
+                    }
                 }
             }
         };
@@ -1915,7 +2051,7 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
             }
             if (sa >= sb) continue;                         // (uniform)
             // ---- mask pass: which of these frames touch which voxel
-            for_contribs(sa, sb, [&](const uint2 &c) {
+            for_contribs(sa, sb, [&](const uint2 &c, int &) {
                 const unsigned f = ((c.x >> 15) & 255u) - (unsigned)F;
                 atomicOr(&vm[(f >> 5) * 256u + (c.x & 127u)], 1u << (f & 31u));
             });
@@ -1974,8 +2110,9 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                         return (int)mw[128 + v] + __popc(mw[v] & (f >> 5 ? wh : wl) & ((1u << (f & 31u)) - 1u));
                     };
                     // ---- pass 1: W, S2 of every cell
-                    for_contribs(ea, eb, [&](const uint2 &c) {
+                    for_contribs(ea, eb, [&](const uint2 &c, int &kept) {
                         const int ci = cell_of(c);
+                        kept = ci;
                         const float w = __uint_as_float(c.y);
                         atomicAdd(&Wc[ci], to_fixed(w, fx_c));
                         atomicAdd(&Sc[ci], to_fixed(w * w, fx_c));
@@ -1985,8 +2122,8 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                     // ---- pass 2a: per cell g = iw / W, a = 1 - iw S2 / W (every thread takes cells)
                     const int used = misc[M_TOT];
                     for (int i = tid; i < used; i += NT) {
-                        const float rW = __builtin_amdgcn_rcpf((float)Wc[i] * fx_inv);
-                        float2 ga; ga.x = iw * rW; ga.y = 1.0f - iw * (((float)Sc[i] * fx_inv) * rW);
+                        const float rW = __builtin_amdgcn_rcpf(u64_to_float(Wc[i]) * fx_inv);
+                        float2 ga; ga.x = iw * rW; ga.y = 1.0f - iw * ((u64_to_float(Sc[i]) * fx_inv) * rW);
                         *reinterpret_cast<float2 *>(Wc + i) = ga;
                         Sc[i] = 0ull;
                     }
@@ -2023,8 +2160,8 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                     __syncthreads();
                     MF_STAMP(4)
                     // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1; an invalid class id adds nothing)
-                    for_contribs(ea, eb, [&](const uint2 &c) {
-                        const int ci = cell_of(c);
+                    for_contribs(ea, eb, [&](const uint2 &c, int &kept) {
+                        const int ci = kept >= 0 ? kept : cell_of(c);
                         const float w = __uint_as_float(c.y), term = (w * w) * klow(Wc, ci);
                         unsigned q = (unsigned)(term * du_scale);
                         if (q == 0u && term > 0.0f) q = 1u;
@@ -2062,14 +2199,14 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                     *reinterpret_cast<uint4 *>(Du + 4u * j) = make_uint4(0u, 0u, 0u, 0u);
                     const unsigned sv0 = pki & 127u, cross = (pki >> 7) & 7u;
                     float ak[4];
-                    if (C >= 4) {                           // (uniform) a float4 spans two voxels at most
+                    if (F4 > 1 || C >= 4) {                 // (F4 > 1: C > 8, known when compiled) a float4 spans two voxels at most
                         const float a0 = atot[sv0], a1 = atot[(sv0 + 1u) & 127u];
                         ak[0] = a0; ak[1] = cross > 1u ? a0 : a1; ak[2] = cross > 2u ? a0 : a1; ak[3] = cross > 3u ? a0 : a1;
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) ak[k] = atot[div_magic(4u * j + k, P.magicC) & 127u];
                     }
-                    const bool changed = (dq.x | dq.y | dq.z | dq.w) != 0u || ak[0] != 1.0f || ak[3] != 1.0f || (C < 4 && (ak[1] != 1.0f || ak[2] != 1.0f));
+                    const bool changed = (dq.x | dq.y | dq.z | dq.w) != 0u || ak[0] != 1.0f || ak[3] != 1.0f || (F4 == 1 && C < 4 && (ak[1] != 1.0f || ak[2] != 1.0f));
                     if (((rows_in >> i) & 1u) && changed) {
                         const v2f d01 = (v2f){(float)dq.x, (float)dq.y} * (v2f){du_inv, du_inv};
                         const v2f d23 = (v2f){(float)dq.z, (float)dq.w} * (v2f){du_inv, du_inv};
@@ -2975,7 +3112,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     const bool merged_batch = FRONT == 0 && P.G == 1 && P.n_frames >= dense_min_frames;
     const bool use_dense = (dense_tiles || merged_batch) && sv == DENSE_SV && P.s2 == 3 && P.feat_kind != MF_FEAT_DENSE_F32 && P.vec4 &&
                        dlds <= (size_t)dev.lds_per_cu && (P.G + dgc - 1) / dgc <= DENSE_MAX_CHUNKS;
-    if (P.meta && !use_dense) return fail(MF_ERR_INVALID, "internal: contributions were chosen for a call no integer tile kernel takes");
+    if (P.meta && !use_dense) return fail(MF_ERR_INVALID, "internal: a tile-local entry format was chosen for a call no integer tile kernel takes");
     const int dnt = dense_nt >= 1024 ? 1024 : 512;
     int dper = (int)((size_t)dev.lds_per_cu / dlds);
     if (dper > 2048 / dnt) dper = 2048 / dnt;
@@ -2998,8 +3135,13 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     if (blocks_cells > P.n_tiles) blocks_cells = P.n_tiles;
 
     const int list_dense_tv = (use_dense || use_cells ? 1 << sv : 0) | (use_dense ? 1 << 20 : 0) | (use_cells ? 1 << 21 : 0) |
-                              (use_dense && dense_forced ? 1 << 22 : 0) | (use_cells && cells_forced && !dense_forced ? 1 << 23 : 0) |
-                              (P.meta ? 1 << 24 : 0);
+                              (use_dense && dense_forced ? 1 << 22 : 0);
+    // entry format of a call in a tile-local format: the probe's choice, unless only fuse_dense_kernel is offered or a
+    // kernel is forced (MF_DENSE_FORCE / MF_CELLS_FORCE: dev / tests)
+    // MF_FORMAT=contributions / records overrides the probe per call (read at every call: tests set it per case)
+    const char *fmt_env = getenv("MF_FORMAT");
+    const int fmt_env_force = !fmt_env ? 0 : fmt_env[0] == 'c' ? 1 : fmt_env[0] == 'r' ? 2 : 0;
+    P.fmt_force = !P.meta ? 0 : (!use_cells || dense_forced) ? 2 : cells_forced ? 1 : fmt_env_force;
     ListMap LM;
     LM.ticket = P.ticket; LM.active = P.active; LM.items = (int *)(ws + L.items);
     LM.split_min = single ? (dense ? 0x7fffffff : split_min()) : 0; LM.split_slots = L.split_slots;
@@ -3019,6 +3161,12 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     prof_mark(0, st);
     // cursor .. ticket (.. split scratch) are contiguous: one memset
     MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, (single ? L.active : L.slot_count) - L.cursor, st));
+    if (FRONT == 0 && P.meta && P.fmt_force == 0) {
+        // which entry format the call's data asks for: eight patches per frame are looked at (use_contributions)
+        const int n_probe = 8;
+        hipLaunchKernelGGL(probe_kernel, dim3(n_probe, (unsigned)P.n_frames), dim3(BIN_THREADS), 0, st, P, n_probe);
+        MF_LAUNCH_CHECK("probe_kernel");
+    }
     P.absmax = FRONT == 0 && single && dense ? (unsigned *)(P.ticket + FEAT_ABSMAX) : nullptr;     // found by count_kernel itself
     hipLaunchKernelGGL(count_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
@@ -3038,7 +3186,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     {
         ListParams LP;
         LP.cursor = P.cursor; LP.n_tiles = P.n_tiles; LP.G = P.G; LP.split_part = split_part();
-        LP.nt1 = P.nt1; LP.nt2 = P.nt2; LP.s0 = P.s0; LP.s1 = P.s1; LP.s2 = P.s2; LP.meta = P.meta;
+        LP.nt1 = P.nt1; LP.nt2 = P.nt2; LP.s0 = P.s0; LP.s1 = P.s1; LP.s2 = P.s2; LP.meta = P.meta; LP.fmt_force = P.fmt_force;
         LP.nonempty = P.ticket + SPLIT_NONEMPTY;
         LP.map[0] = LM;
         const int n_lists = mc && mc->role == 0 ? mc->n_lists : 0;

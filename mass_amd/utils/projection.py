@@ -262,8 +262,13 @@ def fuse_frames(bins_x, bins_y, bins_z, cam_rays, poses, depth, features, featur
     stream = current_stream(fm.device)
     step = _lib.MAX_FRAMES_PER_CALL if sequential else B
     for b0 in range(0, B, step):
-        if b0 > 0 and label_status is not None and int(label_status.reshape(-1)[0]) != 0:
-            break            # a class id out of range has been reported: no further part of the batch is applied
+        if b0 > 0 and label_status is not None:
+            # a batch of more than 256 frames is issued in parts: the earlier part's kernels are waited for before its
+            # status word is read (the word is written by the device; unwaited, the check almost never saw it), so that
+            # no part behind an offending one is applied.  Costs a wait only for such batches.
+            torch.cuda.current_stream(fm.device).synchronize()
+            if int(label_status.reshape(-1)[0]) != 0:
+                break
         nb = min(step, B - b0)
         fr.n_frames = nb
         fr.poses = poses[b0:].data_ptr()

@@ -68,12 +68,14 @@ def test_sparse_batches_take_the_cells_kernel_and_match_the_oracle(device, kind,
 
 
 @pytest.mark.parametrize("kind,C,iw", [("label", 7, 0.5), ("label", 54, 1.0), ("ones", 1, 0.5)])
-def test_tiles_whose_cells_do_not_fit_take_their_frames_in_windows(device, kind, C, iw):
+def test_tiles_whose_cells_do_not_fit_take_their_frames_in_windows(device, kind, C, iw, monkeypatch):
     """64 frames from almost the same place onto a 32^3 map: every frame touches most voxels of the tiles in
-    front of the cameras (~100 cells per tile and frame, far more than fit), the point density stays below the
-    dense kernel's threshold.  The later windows rescale the integer deltas of the earlier ones; the map starts
-    from random values."""
+    front of the cameras (~100 cells per tile and frame, far more than fit).  The library's probe would give such
+    a call - tens of points of a pixel patch in one tile - to fuse_dense_kernel; MF_FORMAT=contributions (read per
+    call) keeps it with fuse_cells_kernel, whose windows this is about.  The later windows rescale the integer
+    deltas of the earlier ones; the map starts from random values."""
     from mass_amd import _lib
+    monkeypatch.setenv("MF_FORMAT", "contributions")
     H, W, M, n = 48, 64, 32, 64
     lay, ref = layers(device, kind, C, H, W, M, 0.1, iw)
     g = torch.Generator().manual_seed(2)
@@ -139,3 +141,31 @@ def test_blend_weight_above_one_goes_to_the_float_tile_kernel(device):
     fr = sparse_frames(n, H, W, C, seed=13, dmax=1.5)
     run_both(lay, ref, fr, slice(0, n), "label", C)
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), rtol=2e-4, what="iw 1.25")
+
+
+@pytest.mark.parametrize("scene", ["unrelated", "room"])
+@pytest.mark.parametrize("fmt", ["contributions", "records", None])
+def test_either_entry_format_gives_the_oracle_map(device, monkeypatch, scene, fmt):
+    """The probe's choice of the tile-local entry format (contributions -> fuse_cells_kernel, 16-byte records ->
+    fuse_dense_kernel) only decides the speed: forced either way, or left to the probe (None), a batch of unrelated
+    frames and a room trajectory both come out within tolerance of the oracle; left alone, the probe sends the
+    unrelated frames to the cells kernel and the room to the dense one."""
+    from mass_amd import _lib
+    from mass_amd.episodes import room_trajectory
+    if fmt is None:
+        monkeypatch.delenv("MF_FORMAT", raising=False)
+    else:
+        monkeypatch.setenv("MF_FORMAT", fmt)
+    H, W, M, C, n = 60, 80, 64, 9, 12
+    lay, ref = layers(device, "label", C, H, W, M, 0.1)
+    if scene == "unrelated":
+        fr = sparse_frames(n, H, W, C, seed=41, dmax=3.0)
+    else:
+        tr = room_trajectory(n, H, W, seed=2, num_classes=C)
+        fr = {k: tr[k] for k in ("position", "yaw", "elevation", "depth", "semantic")}
+    run_both(lay, ref, fr, slice(0, n), "label", C)
+    mode = last_fuse_mode(lay, n)
+    want = {"contributions": _lib.MODE_CELLS, "records": _lib.MODE_DENSE,
+            None: _lib.MODE_CELLS if scene == "unrelated" else _lib.MODE_DENSE}[fmt]
+    assert mode == want
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"{scene} frames as {fmt or 'the probe chose'}")

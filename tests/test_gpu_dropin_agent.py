@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SCREEN, NUM_CLASSES = 224, 54          # SegmentationConfig.SCREEN_SIZE, NUM_CLASSES of the reference
-MAP = dict(map_height=96, map_width=96, map_depth=32, grid_resolution=0.05)     # (the default 384 x 384 x 96 is covered by test_gpu_reference_shapes.py)
+MAP = dict(map_height=192, map_width=192, map_depth=64, grid_resolution=0.05)    # (the default 384 x 384 x 96 is covered by test_gpu_reference_shapes.py)
 
 
 def test_agent_construction_runs_unchanged(device):
@@ -51,7 +51,7 @@ def test_agent_construction_runs_unchanged(device):
             ref.update(dict(position=tr["position"][t], yaw=tr["yaw"][t], elevation=tr["elevation"][t], depth=tr["depth"][t],
                             features=torch.nn.functional.one_hot(tr["semantic"][t].long(), NUM_CLASSES).float()))
         assert resnet0.data.is_cuda and resnet1.data.is_cuda, "a CPU-built layer adopts the HIP device at its first update"
-        assert tuple(resnet0.data.shape) == (96, 96, 32, 256) and float(resnet0.data.abs().sum()) > 0
+        assert tuple(resnet0.data.shape) == (192, 192, 64, 256) and float(resnet0.data.abs().sum()) > 0
         from conftest import assert_map_close
         assert_map_close(semantic0.data.cpu().numpy(), ref.data.numpy(), what="semantic map of the replayed step")
         # agent.py:435-444
