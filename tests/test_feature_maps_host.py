@@ -57,3 +57,35 @@ def test_cpu_layers_fail_loudly_instead_of_falling_back():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         update_feature_maps(maps, obs)
     update_feature_maps({}, obs)                      # nothing selected: nothing to do
+
+
+def test_pose_cache_is_replaced_and_read_as_one_entry():
+    """BaseProjectionLayer._poses keeps the last single-frame pose for the other maps of a simulator step.  Two host
+    threads that ask for different poses at the same time must each get the pose of their own key: the cache is one
+    (key, pose) tuple (with key and pose in two dict entries, one thread's key could meet the other's pose)."""
+    import threading
+    import numpy as np
+    import torch
+    from mass_amd.nn.base_projection_layer import BaseProjectionLayer
+    from mass_amd.utils.projection import spherical_to_cartesian, pack_poses
+    lay = BaseProjectionLayer(camera_height=8, camera_width=8, map_height=4, map_width=4, map_depth=8)
+    poses = [(torch.tensor([0.1 * k, -0.2, 0.3]), torch.tensor(0.05 * k + 0.7 * t), torch.tensor(-0.5)) for t in range(2)
+             for k in range(16)]
+    want = {}
+    for pos, yaw, el in poses:
+        both = spherical_to_cartesian(torch.stack([yaw, yaw]), torch.stack([el, el + np.pi / 2]))
+        want[(float(pos[0]), float(yaw))] = pack_poses(pos.reshape(1, 3), both[:1], both[1:])
+    errors = []
+
+    def work(t):
+        for rep in range(300):
+            for pos, yaw, el in poses[16 * t:16 * t + 16]:
+                got = lay._poses(pos, yaw, el)
+                if not torch.equal(got, want[(float(pos[0]), float(yaw))]):
+                    errors.append((t, float(pos[0]), float(yaw)))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
