@@ -169,3 +169,26 @@ def test_either_entry_format_gives_the_oracle_map(device, monkeypatch, scene, fm
             None: _lib.MODE_CELLS if scene == "unrelated" else _lib.MODE_DENSE}[fmt]
     assert mode == want
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"{scene} frames as {fmt or 'the probe chose'}")
+
+
+@pytest.mark.parametrize("C,my,mx", [(24, 64, 64), (60, 64, 64), (54, 30, 34), (3, 22, 26)])
+def test_other_channel_counts_and_maps_that_are_no_multiple_of_the_tile(device, monkeypatch, C, my, mx):
+    """Every float4-slot instantiation of fuse_cells_kernel (C <= 8, 16, 32, 56, 64) and maps whose height / width are
+    no multiples of four (the rows of a border tile that lie outside the map are neither read nor written).  The small
+    map concentrates the points: MF_FORMAT keeps the call with the cells kernel, which this is about."""
+    monkeypatch.setenv("MF_FORMAT", "contributions")
+    from oracle import massref as orc
+    from mass_amd import _lib
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    H, W, n = 60, 80, 10
+    kw = dict(camera_height=H, camera_width=W, map_height=my, map_width=mx, map_depth=32, grid_resolution=0.1, interpolation_weight=0.5)
+    lay = SemanticProjectionLayer(feature_size=C, **kw).train().to(device)
+    ref = orc.RefProjectionLayer(feature_size=C, **kw)
+    g = torch.Generator().manual_seed(100 + C + my)
+    init = torch.rand(my, mx, 32, C, generator=g) * (torch.rand(my, mx, 32, 1, generator=g) < 0.3)
+    lay.data.copy_(init)
+    ref.data.copy_(init)
+    fr = sparse_frames(n, H, W, C, seed=C + mx, dmax=2.5, spread=0.2)
+    run_both(lay, ref, fr, slice(0, n), "label", C)
+    assert last_fuse_mode(lay, n) == _lib.MODE_CELLS
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"C={C} map {my}x{mx}x32")
