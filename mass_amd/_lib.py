@@ -21,7 +21,7 @@ MODE_SEQUENTIAL, MODE_MERGED = 0, 1
 METRIC_L2, METRIC_L2_GEMM, METRIC_COSINE = 0, 1, 2
 MAX_FRAMES_PER_CALL = 256
 ABI_VERSION = 5
-MODE_TILES, MODE_DENSE, MODE_CELLS = 0, 2, 3
+MODE_TILES, MODE_DENSE, MODE_CELLS, MODE_CELLS_AGG = 0, 2, 3, 4
 MAX_MAPS_PER_CALL = 4          # mf_fuse_frame_maps          # mf_fuse_last_mode
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,

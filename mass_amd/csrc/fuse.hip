@@ -94,7 +94,7 @@ struct FuseParams {
     int gc;                    // frames per chunk in the tile kernel
     int vec4;                  // final pass may use 16-byte accesses
     int meta;                  // entries in a tile-local format (all-integer tile kernels, no aux words): contributions or meta records, see use_contributions
-    int fmt_force;             // 0: the probe decides, 1: contributions, 2: records (only one of the two kernels is offered; dev / tests)
+    int fmt_force;             // entry format of a tile-local call: see entry_format
     unsigned magicC;           // ceil(2^32 / C) (0 when C == 1)
     // workspace
     int *cursor;               // [n_keys + 1]
@@ -286,13 +286,23 @@ constexpr uint32_t EMPTY = 0xffffffffu;
 // fuse_dense_kernel, a batch of unrelated frames (about one point per tile) is expanded into contributions for
 // fuse_cells_kernel.  A function of the call's data alone.
 constexpr int PROBE_POINTS = ABORT_SLOT + 10, PROBE_TILES = ABORT_SLOT + 11;
-constexpr int FORMAT_SLOT = ABORT_SLOT + 12;    // diagnostics: 1 = contributions, 0 = records (tile_list_kernel)
+constexpr int FORMAT_SLOT = ABORT_SLOT + 12;    // diagnostics: the call's entry format, FMT_* (tile_list_kernel)
 constexpr int PROBE_DENSE_RATIO = 8;            // points per distinct tile of a patch from which a scene counts as real
+// Entry format of a call bucketed on 4 x 4 x 8 tiles.  fmt_force: 0 the probe decides between contributions (sparse) and records
+// (real scene), 1 contributions, 2 records, 3 aggregated entries, 4 the probe decides between contributions and aggregated entries.
+constexpr int FMT_RECORDS = 0, FMT_CONTRIB = 1, FMT_AGG = 2;
+__device__ __forceinline__ int entry_format(const int *ticket, int meta, int fmt_force)
+{
+    if (!meta) return FMT_RECORDS;
+    if (fmt_force == 1) return FMT_CONTRIB;
+    if (fmt_force == 2) return FMT_RECORDS;
+    if (fmt_force == 3) return FMT_AGG;
+    const bool sparse = ticket[PROBE_POINTS] < PROBE_DENSE_RATIO * ticket[PROBE_TILES];
+    return sparse ? FMT_CONTRIB : fmt_force == 4 ? FMT_AGG : FMT_RECORDS;
+}
 __device__ __forceinline__ bool use_contributions(const int *ticket, int meta, int fmt_force)
 {
-    if (!meta) return false;
-    if (fmt_force) return fmt_force == 1;
-    return ticket[PROBE_POINTS] < PROBE_DENSE_RATIO * ticket[PROBE_TILES];
+    return entry_format(ticket, meta, fmt_force) == FMT_CONTRIB;
 }
 
 // The table pays when the keys of a block repeat (neighbouring pixels of a real scene share their tiles: tens of points
@@ -491,6 +501,7 @@ __global__ __launch_bounds__(BIN_THREADS) void count_kernel(FuseParams P)
     __shared__ uint32_t hkey[HS];
     __shared__ int hcnt[HS];
     __shared__ int hfill;
+    if (FRONT == 0 && entry_format(P.ticket, P.meta, P.fmt_force) == FMT_AGG) return;      // bucket_agg_kernel<false> takes the call (uniform)
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
     if (threadIdx.x == 0) hfill = 0;
     __syncthreads();
@@ -566,6 +577,7 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
     __shared__ uint32_t hkey[HS];
     __shared__ int hcnt[HS];
     __shared__ int hfill;
+    if (FRONT == 0 && entry_format(P.ticket, P.meta, P.fmt_force) == FMT_AGG) return;      // bucket_agg_kernel<true> takes the call (uniform)
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
     if (threadIdx.x == 0) hfill = 0;
     __syncthreads();
@@ -685,6 +697,199 @@ __global__ __launch_bounds__(BIN_THREADS) void scatter_kernel(FuseParams P)
     }
 }
 
+// w * 2^shift as a 64-bit integer (truncated), for 0 <= w < 2^(40 - shift + ...): built from the
+// float's bits with one 64-bit shift instead of the seven-instruction float -> u64 conversion.
+// fx_c = 182 - shift; a result below one unit (or w == 0) comes out as 0.
+__device__ __forceinline__ unsigned long long to_fixed(float w, int fx_c)
+{
+    const unsigned b = __float_as_uint(w);
+    const unsigned m = (b & 0x7fffffu) | 0x800000u;             // 24-bit significand
+    int amt = fx_c - (int)(b >> 23);                            // (m << 32) >> amt == m * 2^(e - 150 + shift)
+    amt = amt > 63 ? 63 : amt;                                  // m << 32 < 2^56, so 63 yields 0
+    return ((unsigned long long)m << 32) >> amt;
+}
+
+// ----------------------------------------------------------------------------
+// AGGREGATED entries (round 4): collision compaction for real scenes
+// ----------------------------------------------------------------------------
+// In a real scene the 256 points of a 16 x 16 pixel patch land on a few dozen voxels: 30-140 corners of a frame on
+// the same (voxel, class).  The all-integer tile kernels only need, per (voxel, class, frame), the SUMS W = sum w and
+// S2 = sum w^2 of those corners (W and S2 of the voxel's cell are sums over the classes, the delta of (voxel, class) is
+// t_f * S2).  So for calls the probe finds to be a real scene the two bucketing kernels aggregate a block's 2,048
+// corners per (tile, frame, voxel, class) in LDS before anything is written, and the tile kernel (fuse_cells_kernel<AGG>)
+// reads one 16-byte entry per group instead of one 16-byte record per (point, tile):
+//   x  bits  0..6 voxel inside the tile, 7..14 class id (255 = outside [0, C)), 15..22 frame, 23..31 W bits 32..40
+//   y  W bits 0..31      z, w  S2 (64 bits)
+// W is the exact integer sum of to_fixed(w) with 32 fraction bits, S2 that of to_fixed(w * w) with 55 (a block puts at
+// most 256 x 1.0 on one voxel: below 2^41 / 2^63), so the entries - and with them the map - are run-to-run identical.
+// S2 needs its 55 bits: a voxel that a frame touches with ONE far corner of weight w ~ 1e-7 receives iw * w^2 / W = iw * w,
+// which is not small against the map's tolerance although w^2 ~ 1e-14 is (with 40 fraction bits such corners were lost:
+// measured, 3e-6 off on the border voxels of a room); W only enters as S2 / W and 1 / W, where 2^-32 absolute is plenty.
+// count (SCATTER = false) and scatter (SCATTER = true) must agree on the number of entries of every bucket, whatever
+// the order their threads run in: the table is DIRECT MAPPED and a slot goes to the SMALLEST key that hashes to it
+// (atomicMin, order independent).  Corners whose key won their slot are summed there and leave as ONE entry; a
+// corner that lost is written as an entry of its own.  Both kernels see the same keys, hence the same winners.
+constexpr int AGG_BITS = 10, AGG_SLOTS = 1 << AGG_BITS;
+constexpr unsigned long long AGG_EMPTY = ~0ull;
+constexpr int AGG_FW = 32, AGG_FS = 55;            // fraction bits of an entry's W / S2
+#ifndef AGG_DEFAULT
+#define AGG_DEFAULT 0
+#endif
+
+__device__ __forceinline__ int agg_slot(unsigned long long k)
+{
+    const uint32_t x = ((uint32_t)k ^ ((uint32_t)(k >> 32) * 0x85ebca6bu) ^ ((uint32_t)(k >> 15) * 0x27d4eb2fu)) * 2654435761u;
+    return (int)(x >> (32 - AGG_BITS));
+}
+__device__ __forceinline__ uint4 make_agg_entry(unsigned hdr, unsigned long long W, unsigned long long S)
+{
+    uint4 e;
+    e.x = hdr | ((unsigned)(W >> 32) << 23);
+    e.y = (unsigned)W;
+    e.z = (unsigned)S;
+    e.w = (unsigned)(S >> 32);
+    return e;
+}
+__device__ __forceinline__ unsigned long long agg_W(const uint4 &e) { return (unsigned long long)e.y | ((unsigned long long)(e.x >> 23) << 32); }
+__device__ __forceinline__ unsigned long long agg_S(const uint4 &e) { return (unsigned long long)e.z | ((unsigned long long)e.w << 32); }
+
+template <bool SCATTER>
+__global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
+{
+    __shared__ unsigned long long akey[AGG_SLOTS];
+    __shared__ unsigned long long aW[SCATTER ? AGG_SLOTS : 1], aS[SCATTER ? AGG_SLOTS : 1];
+    __shared__ uint32_t hkey[HS];
+    __shared__ int hcnt[HS];
+    __shared__ int hfill;
+    if (entry_format(P.ticket, P.meta, P.fmt_force) != FMT_AGG) return;        // count_kernel / scatter_kernel take the call (uniform)
+    for (int s = threadIdx.x; s < AGG_SLOTS; s += BIN_THREADS) {
+        akey[s] = AGG_EMPTY;
+        if (SCATTER) { aW[s] = 0ull; aS[s] = 0ull; }
+    }
+    for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
+    if (threadIdx.x == 0) hfill = 0;
+    __syncthreads();
+    const long long idx = point_index<0>(P, BIN_THREADS);
+    Point pt;
+    bool ok = false;
+    if (!SCATTER) {
+        if (idx >= 0) {
+            uint32_t aux = 0;
+            ok = get_point<0>(P, idx, pt, aux);
+            if (P.label_status && P.feat_kind >= MF_FEAT_LABEL_U8 && P.feat_kind <= MF_FEAT_LABEL_I64 && aux >= (uint32_t)P.C) {
+                *P.label_status = 1;                    // (as in count_kernel)
+                P.ticket[ABORT_SLOT] = 1;
+            }
+            uint4 r = make_record(pt);
+            if (!ok) r.y = 0xffffffffu;
+            P.pts[idx] = r;
+        }
+    } else {
+        uint4 r = make_uint4(0u, 0xffffffffu, 0u, 0u);
+        if (idx >= 0) r = P.pts[idx];
+        ok = (r.y & 0x3fffffffu) != 0x3fffffffu;
+        if (ok) {
+            const unsigned rm = 0x3fffffffu;
+            pt.k0 = r.x & 1023; pt.k1 = (r.x >> 10) & 1023; pt.k2 = (r.x >> 20) & 1023;
+            pt.r0 = __uint_as_float(r.y & rm); pt.r1 = __uint_as_float(r.z & rm); pt.r2 = __uint_as_float(r.w & rm);
+            pt.group = P.G == 1 ? 0 : (int)blockIdx.y;
+        }
+    }
+    // the eight corners: key = (bucket of the corner's tile, class id, voxel inside the tile), slot, weight
+    unsigned long long ck[8];
+    float cw[8];
+    unsigned lose = 0u;
+    if (ok) {
+        uint32_t label = 0u;
+        if (P.feat_kind != MF_FEAT_ONES) {
+            const Pix px = patch_pixel(P);
+            label = read_label(P.feat, P.feat_kind, feature_pixel((int)blockIdx.y, px.y, px.x, P.fh, P.fw, P.rep_y, P.rep_x));
+        }
+        const unsigned low = (label > 255u ? 255u : label) << 7;
+        TileKeys K;
+        point_keys8(P, pt, K);
+        const float w0[2] = {K.a0.wlo, K.a0.whi}, w1[2] = {K.a1.wlo, K.a1.whi}, w2[2] = {K.a2.wlo, K.a2.whi};
+        const unsigned x0[2] = {(unsigned)(K.a0.lo & 3) << 5, (unsigned)(K.a0.hi & 3) << 5};
+        const unsigned x1[2] = {(unsigned)(K.a1.lo & 3) << 3, (unsigned)(K.a1.hi & 3) << 3};
+        const unsigned x2[2] = {(unsigned)(K.a2.lo & 7), (unsigned)(K.a2.hi & 7)};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ca = c >> 2, cb = (c >> 1) & 1, cd = c & 1;
+            // (w0 * w1) * w2 + 1e-9, the reference's product order (projection.py:319-323); corner c lies in the tile of key position c & straddle
+            cw[c] = 1e-9f + (w0[ca] * w1[cb]) * w2[cd];
+            ck[c] = ((unsigned long long)K.key[c & K.straddle] << 15) | low | x0[ca] | x1[cb] | x2[cd];
+            atomicMin(&akey[agg_slot(ck[c])], ck[c]);
+        }
+    }
+    __syncthreads();
+    int lslot[8], lrank[8];
+    {
+        const bool open = hash_open(&hfill);
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int s = agg_slot(ck[c]);
+                lslot[c] = -1; lrank[c] = 0;
+                if (akey[s] == ck[c]) {
+                    if (SCATTER) {
+                        atomicAdd(&aW[s], to_fixed(cw[c], 182 - AGG_FW));
+                        atomicAdd(&aS[s], to_fixed(cw[c] * cw[c], 182 - AGG_FS));
+                    }
+                } else {
+                    lose |= 1u << c;
+                    const uint32_t tk = (uint32_t)(ck[c] >> 15);
+                    lslot[c] = hash_insert(hkey, hcnt, &hfill, tk, lrank[c], open, 1);
+                    if (!SCATTER && lslot[c] < 0) atomicAdd(&P.cursor[tk], 1);
+                }
+            }
+        }
+    }
+    // one entry per claimed slot
+    int sslot[AGG_SLOTS / BIN_THREADS], srank[AGG_SLOTS / BIN_THREADS];
+    {
+        const bool open = hash_open(&hfill);
+#pragma unroll
+        for (int i = 0; i < AGG_SLOTS / BIN_THREADS; ++i) {
+            const unsigned long long k = akey[threadIdx.x + BIN_THREADS * i];
+            sslot[i] = -1; srank[i] = 0;
+            if (k != AGG_EMPTY) {
+                const uint32_t tk = (uint32_t)(k >> 15);
+                sslot[i] = hash_insert(hkey, hcnt, &hfill, tk, srank[i], open, 1);
+                if (!SCATTER && sslot[i] < 0) atomicAdd(&P.cursor[tk], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        for (int s = threadIdx.x; s < HS; s += BIN_THREADS)
+            if (hkey[s] != EMPTY) atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
+        return;
+    }
+    for (int s = threadIdx.x; s < HS; s += BIN_THREADS)
+        if (hkey[s] != EMPTY) hcnt[s] = atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
+    __syncthreads();
+    const unsigned fbits = (unsigned)(P.G == 1 ? 0 : (int)blockIdx.y) << 15;
+#pragma unroll
+    for (int i = 0; i < AGG_SLOTS / BIN_THREADS; ++i) {
+        const int s = threadIdx.x + BIN_THREADS * i;
+        const unsigned long long k = akey[s];
+        if (k != AGG_EMPTY) {
+            const uint32_t tk = (uint32_t)(k >> 15);
+            const int pos = sslot[i] >= 0 ? hcnt[sslot[i]] + srank[i] : atomicAdd(&P.cursor[tk], 1);
+            P.rec[pos] = make_agg_entry(((unsigned)k & 0x7fffu) | fbits, aW[s], aS[s]);
+        }
+    }
+    if (lose) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (lose & (1u << c)) {
+                const uint32_t tk = (uint32_t)(ck[c] >> 15);
+                const int pos = lslot[c] >= 0 ? hcnt[lslot[c]] + lrank[c] : atomicAdd(&P.cursor[tk], 1);
+                P.rec[pos] = make_agg_entry(((unsigned)ck[c] & 0x7fffu) | fbits, to_fixed(cw[c], 182 - AGG_FW), to_fixed(cw[c] * cw[c], 182 - AGG_FS));
+            }
+    }
+}
+
 // ----------------------------------------------------------------------------
 // exclusive scan of cursor[0 .. n] (n = n_keys + 1 items, last one is 0)
 // ----------------------------------------------------------------------------
@@ -780,7 +985,7 @@ __device__ __forceinline__ int cell_class(int n)     // n >= 1
     const int l = 31 - __clz(n), key = 2 * l + (l > 0 ? (n >> (l - 1)) & 1 : 0);
     return max(0, CELL_CLASSES - 1 - key);
 }
-constexpr int MODE_TILES = 0, MODE_DENSE = 2, MODE_CELLS = 3;
+constexpr int MODE_TILES = 0, MODE_DENSE = 2, MODE_CELLS = 3, MODE_CELLS_AGG = 4;      // (4: fuse_cells_kernel over aggregated entries)
 constexpr int SINGLE_DENSE_MAX_C = 16;          // dense features take the single-pass path up to this many channels
 constexpr int SINGLE_MIN_MEAN = 96;       // class ids: mean records per non-empty tile below which a call stays with the tile kernel
 constexpr int SPLIT_PARTS_MAX = 64;
@@ -822,14 +1027,14 @@ __global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
     // and tile voxel - half a record per voxel and frame or more is a real scene.
     // dense_tv: low bits the tiles' voxel count, bit 20: fuse_dense_kernel is offered the call, bit 21: fuse_cells_kernel is
     const bool dense_ok = dense_tv & (1 << 20), cells_ok = dense_tv & (1 << 21);
-    const bool contrib = use_contributions(ticket, LP.meta, LP.fmt_force);
+    const int fmt = entry_format(ticket, LP.meta, LP.fmt_force);
     const long long total = cursor[n_tiles * G];
     const long long half = (long long)*nonempty * ((dense_tv & 0xfffff) ? (dense_tv & 0xfffff) : 512) / 2;
-    const bool dense = dense_ok && (LP.meta ? !contrib : (total >= half || (dense_tv & (1 << 22))));
-    const int tile_mode = dense ? MODE_DENSE : contrib && cells_ok ? MODE_CELLS : MODE_TILES;
+    const bool dense = dense_ok && (LP.meta ? fmt == FMT_RECORDS : (total >= half || (dense_tv & (1 << 22))));
+    const int tile_mode = dense ? MODE_DENSE : fmt != FMT_RECORDS && cells_ok ? (fmt == FMT_AGG ? MODE_CELLS_AGG : MODE_CELLS) : MODE_TILES;
     if (t == 0) {
         ticket[MODE_SLOT] = tile_mode;
-        ticket[FORMAT_SLOT] = contrib ? 1 : 0;
+        ticket[FORMAT_SLOT] = fmt;
         ticket[HINT_SLOT] = (int)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
         ticket[HINT_SLOT + 1] = (int)(half > 0x7fffffffLL ? 0x7fffffffLL : half);
         // every tile kernel deals its first items statically (see there) and has a work counter of its own
@@ -859,7 +1064,7 @@ __global__ __launch_bounds__(256) void tile_list_kernel(ListParams LP)
         return;                                     // nothing is listed for the tile kernel
     }
     const int lane = threadIdx.x & 63;
-    if (tile_mode == MODE_CELLS) {
+    if (tile_mode == MODE_CELLS || tile_mode == MODE_CELLS_AGG) {
         // fuse_cells_kernel's list: fine load classes; a work item carries what the kernel would otherwise look up in a
         // chain of dependent loads: first entry, count, tile origin.  The block's tiles are ranked per class in LDS, so the
         // block issues ONE returning global atomic per class it holds (all in flight together).
@@ -959,18 +1164,6 @@ __device__ unsigned long long g_stamps[16];
         stamp_acc[i] += _t - t_last;                                                  \
         t_last = _t;                                                                  \
     }
-
-// w * 2^shift as a 64-bit integer (truncated), for 0 <= w < 2^(40 - shift + ...): built from the
-// float's bits with one 64-bit shift instead of the seven-instruction float -> u64 conversion.
-// fx_c = 182 - shift; a result below one unit (or w == 0) comes out as 0.
-__device__ __forceinline__ unsigned long long to_fixed(float w, int fx_c)
-{
-    const unsigned b = __float_as_uint(w);
-    const unsigned m = (b & 0x7fffffu) | 0x800000u;             // 24-bit significand
-    int amt = fx_c - (int)(b >> 23);                            // (m << 32) >> amt == m * 2^(e - 150 + shift)
-    amt = amt > 63 ? 63 : amt;                                  // m << 32 < 2^56, so 63 yields 0
-    return ((unsigned long long)m << 32) >> amt;
-}
 
 // LDS float add.  ds_add_f32 costs ~80 ns per wave instruction on gfx950 whatever the
 // address pattern; one compare-and-swap round trip on the bit pattern costs ~11 ns when the
@@ -1859,9 +2052,10 @@ __device__ __forceinline__ float u64_to_float(unsigned long long x)
     return __builtin_fmaf((float)(unsigned)(x >> 32), 4294967296.0f, (float)(unsigned)x);
 }
 
-template <int KIND, int F4, bool STAMPS = false>   // F4: float4s per thread and tile (ceil(32 C / 256))
+template <int KIND, int F4, bool STAMPS = false, bool AGG = false>   // F4: float4s per thread and tile (ceil(32 C / 256)); AGG: aggregated 16-byte entries (bucket_agg_kernel)
 __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
 {
+    typedef typename std::conditional<AGG, uint4, uint2>::type Ent;
     extern __shared__ float smem[];
     unsigned long long t_last = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long stamp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
@@ -1882,14 +2076,18 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
     constexpr int M_TOT = 0, M_FIT = 1, M_EA = 2 /* [2] */, M_CS = 8 /* [CELL_CLASSES + 1] list position of the classes' first tiles */,
                   M_CNT = 64 /* [64] inclusive per-frame cell counts */;
     static_assert(M_CS + CELL_CLASSES + 1 <= M_CNT, "look-up words");
-    const uint2 *rec2 = reinterpret_cast<const uint2 *>(P.rec);
+    const Ent *rec2 = reinterpret_cast<const Ent *>(P.rec);
     const int fx_c = 182 - P.fx_shift;
     const float fx_inv = __uint_as_float((unsigned)(127 - P.fx_shift) << 23);  // 2^-shift
     const float du_inv = __uint_as_float((unsigned)(127 - CELLS_FX) << 23);    // 2^-CELLS_FX
     const float du_scale = __uint_as_float((unsigned)(127 + CELLS_FX) << 23);  // 2^CELLS_FX
     const float iw = P.iw;
+    const float as_inv = __uint_as_float((unsigned)(127 - AGG_FS) << 23);      // 2^-AGG_FS
 
-    if (P.ticket[MODE_SLOT] != MODE_CELLS) return;                             // fuse_dense_kernel takes the call (uniform)
+    if (P.ticket[MODE_SLOT] != (AGG ? MODE_CELLS_AGG : MODE_CELLS)) return;    // another tile kernel takes the call (uniform)
+#ifdef CELLS_PRIO_DEF
+    __builtin_amdgcn_s_setprio(CELLS_PRIO_DEF);
+#endif
     // Work list position -> item; tile -1 past the end.  misc[M_CS + c] = list position of class c's first tile; a
     // workgroup's positions only grow, so the class is found by walking on from the last one.
     if (tid == 0) {
@@ -1946,8 +2144,12 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
     // of the tile BEFORE, together with that tile's rows, and taken over at its end: no load whose result is still
     // awaited crosses the loop's back edge (where the compiler, which tracks the counter exactly only in straight-line
     // code, would wait for everything in flight - the rows just requested included).
-    uint2 cache[CELLS_CR], cache_n[CELLS_CR];
-    auto prefetch = [&](int first, int n, uint2 (&q)[CELLS_CR]) {       // unconditional (clamped) loads
+    auto hide = [](Ent &c) {
+        if constexpr (AGG) asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
+        else asm volatile("" : "+v"(c.x), "+v"(c.y));
+    };
+    Ent cache[CELLS_CR], cache_n[CELLS_CR];
+    auto prefetch = [&](int first, int n, Ent (&q)[CELLS_CR]) {       // unconditional (clamped) loads
 #pragma unroll
         for (int j = 0; j < CELLS_CR; ++j) q[j] = rec2[first + min(tid + NT * j, max(n - 1, 0))];
     };
@@ -2007,8 +2209,8 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                 if (t_a + NT * j < eb) {                                        // (uniform)
                     // (the empty asm hides from the compiler that the word is the same in every pass: it would decode all
                     // four once and hold the fields in registers across the tile)
-                    uint2 c = cache[j];
-                    asm volatile("" : "+v"(c.x), "+v"(c.y));
+                    Ent c = cache[j];
+                    hide(c);
                     if (k >= ea && k < eb) body(c, cell_kept[j]);
                 }
             }
@@ -2017,12 +2219,12 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
             int k = max(ea, t_a + NT * CELLS_CR);
             k += ((tid - k) & (NT - 1));                                        // the first k' >= k with k' = tid (mod 256): coalesced trips
             if (k < eb) {
-                uint2 nx[4];
+                Ent nx[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) nx[q] = rec2[min(k + NT * q, eb - 1)];
 #pragma unroll 1
                 for (; k < eb; k += 4 * NT) {
-                    uint2 c[4];
+                    Ent c[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) c[q] = nx[q];
                     if (k + 4 * NT < eb) {                                      // (per thread; clamped: no branch per load)
@@ -2051,7 +2253,7 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
             }
             if (sa >= sb) continue;                         // (uniform)
             // ---- mask pass: which of these frames touch which voxel
-            for_contribs(sa, sb, [&](const uint2 &c, int &) {
+            for_contribs(sa, sb, [&](const Ent &c, int &) {
                 const unsigned f = ((c.x >> 15) & 255u) - (unsigned)F;
                 atomicOr(&vm[(f >> 5) * 256u + (c.x & 127u)], 1u << (f & 31u));
             });
@@ -2104,18 +2306,23 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                 if (ea < eb) {
                     const unsigned wl = (unsigned)wm, wh = (unsigned)(wm >> 32);
                     // cell of a contribution: its voxel's base + the frames of the window below its own
-                    auto cell_of = [&](const uint2 &c) {
+                    auto cell_of = [&](const Ent &c) {
                         const unsigned f = ((c.x >> 15) & 255u) - (unsigned)F, v = c.x & 127u;
                         const unsigned *mw = vm + (f >> 5) * 256u;
                         return (int)mw[128 + v] + __popc(mw[v] & (f >> 5 ? wh : wl) & ((1u << (f & 31u)) - 1u));
                     };
                     // ---- pass 1: W, S2 of every cell
-                    for_contribs(ea, eb, [&](const uint2 &c, int &kept) {
+                    for_contribs(ea, eb, [&](const Ent &c, int &kept) {
                         const int ci = cell_of(c);
                         kept = ci;
-                        const float w = __uint_as_float(c.y);
-                        atomicAdd(&Wc[ci], to_fixed(w, fx_c));
-                        atomicAdd(&Sc[ci], to_fixed(w * w, fx_c));
+                        if constexpr (AGG) {
+                            atomicAdd(&Wc[ci], agg_W(c) << (P.fx_shift - AGG_FW));       // (fx_shift >= 33: make_layout bounds the points)
+                            atomicAdd(&Sc[ci], agg_S(c) >> (AGG_FS - P.fx_shift));       // (fx_shift <= 50)
+                        } else {
+                            const float w = __uint_as_float(c.y);
+                            atomicAdd(&Wc[ci], to_fixed(w, fx_c));
+                            atomicAdd(&Sc[ci], to_fixed(w * w, fx_c));
+                        }
                     });
                     __syncthreads();
                     MF_STAMP(3)
@@ -2160,11 +2367,14 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
                     __syncthreads();
                     MF_STAMP(4)
                     // ---- pass 3: D += t_f * w^2 (the class-id / ones feature is 1; an invalid class id adds nothing)
-                    for_contribs(ea, eb, [&](const uint2 &c, int &kept) {
+                    for_contribs(ea, eb, [&](const Ent &c, int &kept) {
                         const int ci = kept >= 0 ? kept : cell_of(c);
-                        const float w = __uint_as_float(c.y), term = (w * w) * klow(Wc, ci);
+                        const float tf = klow(Wc, ci);
+                        float term;
+                        if constexpr (AGG) term = (u64_to_float(agg_S(c)) * as_inv) * tf;      // the group's sum of w^2 (every corner has w >= 1e-9)
+                        else { const float w = __uint_as_float(c.y); term = (w * w) * tf; }
                         unsigned q = (unsigned)(term * du_scale);
-                        if (q == 0u && term > 0.0f) q = 1u;
+                        if (q == 0u && (AGG ? tf > 0.0f : term > 0.0f)) q = 1u;
                         const unsigned x = (c.x >> 7) & 255u, v = c.x & 127u;
                         const bool xok = KIND == 0 || x < (unsigned)C;
                         atomicAdd(&Du[v * C + (KIND == 0 || !xok ? 0u : x)], xok ? q : 0u);
@@ -2184,7 +2394,10 @@ __global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
         // What was requested at the tile's start is taken in HERE, before this tile's stores are issued: the vector-memory
         // counter retires in order, so behind the stores the wait for these loads would be a wait for the stores' round trip too.
 #pragma unroll
-        for (int j = 0; j < CELLS_CR; ++j) asm volatile("" :: "v"(cache_n[j].x), "v"(cache_n[j].y));
+        for (int j = 0; j < CELLS_CR; ++j) {
+            if constexpr (AGG) asm volatile("" :: "v"(cache_n[j].x), "v"(cache_n[j].y), "v"(cache_n[j].z), "v"(cache_n[j].w));
+            else asm volatile("" :: "v"(cache_n[j].x), "v"(cache_n[j].y));
+        }
 #pragma unroll
         for (int i = 0; i < F4; ++i) {
             if ((unsigned)(i * NT) < n4) {                  // (uniform)
@@ -3125,11 +3338,13 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     static const bool cells_on = env_int("MF_CELLS", 0, 1, 1) != 0;
     static const bool cells_forced = getenv("MF_CELLS_FORCE") != nullptr;
     int cells_cap = 0, cells_per_cu = 1;
+    static const int cells_reserve = env_int("MF_CELLS_RESERVE", 0, 128 * 1024, 8192);          // dev: LDS per CU left to the bucketing kernels beside a commit
+    static const int cells_most = env_int("MF_CELLS_MOST", 1, 3, 2);                            // dev: workgroups per CU beside them
     const bool use_cells = cells_on && dense_tiles && use_dense && sv == CELLS_SV && P.s2 == 3 && P.s0 == 2 && P.G >= 2 &&
                            // (a commit on its own runs beside the bucketing kernels of the next batch: they need a few KB of LDS per CU)
                            // ... and wave slots / registers: two workgroups per CU beside them (headline, pipelined: 24.5 k frames/s
                            // against 20.3 k with three), three when the call has the chip to itself (equal alone: 1.84 / 1.89 ms)
-                           cells_config(P.C, dev.lds_per_cu, phase == 3 ? 0 : 8192, phase == 3 ? 3 : 2, cells_cap, cells_per_cu);
+                           cells_config(P.C, dev.lds_per_cu, phase == 3 ? 0 : cells_reserve, phase == 3 ? 3 : cells_most, cells_cap, cells_per_cu);
     int blocks_cells = dev.cus * cells_per_cu;
     if (blocks_cap > 0 && blocks_cells > blocks_cap) blocks_cells = blocks_cap;
     if (blocks_cells > P.n_tiles) blocks_cells = P.n_tiles;
@@ -3139,9 +3354,22 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     // entry format of a call in a tile-local format: the probe's choice, unless only fuse_dense_kernel is offered or a
     // kernel is forced (MF_DENSE_FORCE / MF_CELLS_FORCE: dev / tests)
     // MF_FORMAT=contributions / records overrides the probe per call (read at every call: tests set it per case)
+    // (MF_FORMAT=aggregated: the aggregated entries of bucket_agg_kernel for every call; MF_AGG=0: real scenes keep records +
+    // fuse_dense_kernel instead of aggregated entries + fuse_cells_kernel)
     const char *fmt_env = getenv("MF_FORMAT");
-    const int fmt_env_force = !fmt_env ? 0 : fmt_env[0] == 'c' ? 1 : fmt_env[0] == 'r' ? 2 : 0;
+    static const bool agg_on = env_int("MF_AGG", 0, 1, AGG_DEFAULT) != 0;
+    const int fmt_env_force = !fmt_env ? (agg_on ? 4 : 0) : fmt_env[0] == 'c' ? 1 : fmt_env[0] == 'r' ? 2 : fmt_env[0] == 'a' ? 3 : (agg_on ? 4 : 0);
     P.fmt_force = !P.meta ? 0 : (!use_cells || dense_forced) ? 2 : cells_forced ? 1 : fmt_env_force;
+    const bool agg_offered = P.meta && (P.fmt_force == 3 || P.fmt_force == 4);
+    // fixed-point fraction bits of the W / S2 sums: the per-voxel, per-frame sum of weights is
+    // below (points per group) * (1 + 1e-9), and must stay below 2^63
+    int fx_shift;
+    {
+        long long per_group = P.G > 1 ? (P.n_points + P.G - 1) / P.G : P.n_points;
+        int bits = 1; while ((1ll << bits) <= per_group) ++bits;
+        fx_shift = 62 - bits; if (fx_shift > 50) fx_shift = 50;
+    }
+
     ListMap LM;
     LM.ticket = P.ticket; LM.active = P.active; LM.items = (int *)(ws + L.items);
     LM.split_min = single ? (dense ? 0x7fffffff : split_min()) : 0; LM.split_slots = L.split_slots;
@@ -3161,7 +3389,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     prof_mark(0, st);
     // cursor .. ticket (.. split scratch) are contiguous: one memset
     MF_HIP_CHECK(hipMemsetAsync(ws + L.cursor, 0, (single ? L.active : L.slot_count) - L.cursor, st));
-    if (FRONT == 0 && P.meta && P.fmt_force == 0) {
+    if (FRONT == 0 && P.meta && (P.fmt_force == 0 || P.fmt_force == 4)) {
         // which entry format the call's data asks for: eight patches per frame are looked at (use_contributions)
         const int n_probe = 8;
         hipLaunchKernelGGL(probe_kernel, dim3(n_probe, (unsigned)P.n_frames), dim3(BIN_THREADS), 0, st, P, n_probe);
@@ -3170,6 +3398,10 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     P.absmax = FRONT == 0 && single && dense ? (unsigned *)(P.ticket + FEAT_ABSMAX) : nullptr;     // found by count_kernel itself
     hipLaunchKernelGGL(count_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("count_kernel");
+    if (FRONT == 0 && agg_offered) {
+        hipLaunchKernelGGL(bucket_agg_kernel<false>, bin_blocks, dim3(BIN_THREADS), 0, st, P);    // returns at once unless the call's format is FMT_AGG (count_kernel returns then)
+        MF_LAUNCH_CHECK("bucket_agg_kernel<count>");
+    }
     if (FRONT != 0 && single && dense) {
         const long long nf = FRONT == 0 ? (long long)P.n_frames * P.fh * P.fw * P.C : P.n_points * P.C;
         hipLaunchKernelGGL(feat_absmax_kernel, dim3((unsigned)((nf + 256 * 16 - 1) / (256 * 16) > 1024 ? 1024 : (nf + 256 * 16 - 1) / (256 * 16))),
@@ -3197,6 +3429,10 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     prof_mark(2, st);
     hipLaunchKernelGGL(scatter_kernel<FRONT>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
     MF_LAUNCH_CHECK("scatter_kernel");
+    if (FRONT == 0 && agg_offered) {
+        hipLaunchKernelGGL(bucket_agg_kernel<true>, bin_blocks, dim3(BIN_THREADS), 0, st, P);
+        MF_LAUNCH_CHECK("bucket_agg_kernel<scatter>");
+    }
     if (mc) MF_HIP_CHECK(hipEventRecord(mc->scattered, st));
     prof_mark(3, st);
     if (g_profile && g_ev_ready && g_prof_stages < PROF_CALLS) ++g_prof_stages;
@@ -3228,13 +3464,7 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     T.size0 = P.size0; T.size1 = P.size1; T.size2 = P.size2; T.C = P.C; T.map = P.map; T.feat = P.feat;
     T.G = P.G; T.iw = P.iw; T.s0 = P.s0; T.s1 = P.s1; T.s2 = P.s2; T.nt1 = P.nt1; T.nt2 = P.nt2;
     T.n_tiles = P.n_tiles; T.magicC = P.magicC; T.gc = P.gc; T.vec4 = P.vec4; T.cursor = P.cursor;
-    // fixed-point fraction bits of the W / S2 sums: the per-voxel, per-frame sum of weights is
-    // below (points per group) * (1 + 1e-9), and must stay below 2^63
-    {
-        long long per_group = P.G > 1 ? (P.n_points + P.G - 1) / P.G : P.n_points;
-        int bits = 1; while ((1ll << bits) <= per_group) ++bits;
-        T.fx_shift = 62 - bits; if (T.fx_shift > 50) T.fx_shift = 50;
-    }
+    T.fx_shift = fx_shift;
     T.ticket = P.ticket; T.active = P.active; T.rec = P.rec; T.aux = P.aux;
     T.ctr = P.ticket;
     T.cells_cap = cells_cap;
@@ -3282,9 +3512,9 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         else ck = f4 <= 1 ? fuse_cells_kernel<1, 1> : f4 <= 2 ? fuse_cells_kernel<1, 2> : f4 <= 4 ? fuse_cells_kernel<1, 4> : f4 <= 7 ? fuse_cells_kernel<1, 7> : fuse_cells_kernel<1, 8>;
         if (stamps && kind == 1 && f4 == 7) ck = fuse_cells_kernel<1, 7, true>;      // (dev: the headline shape)
         const size_t clds = cells_lds_bytes(P.C, cells_cap);
+        static std::mutex mu4;
+        static std::unordered_map<const void *, size_t> granted4;
         {
-            static std::mutex mu4;
-            static std::unordered_map<const void *, size_t> granted4;
             std::lock_guard<std::mutex> lock(mu4);
             size_t &have = granted4[(const void *)ck];
             if (have < clds) {
@@ -3297,6 +3527,23 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         S.light = (const int4 *)(ws + L.light);
         hipLaunchKernelGGL(ck, dim3(blocks_cells), dim3(CELLS_NT), clds, st, S);   // returns at once unless tile_list_kernel chose it
         MF_LAUNCH_CHECK("fuse_cells_kernel");
+        if (agg_offered) {
+            void (*ak)(TileParams);
+            if (kind == 0) ak = fuse_cells_kernel<0, 1, false, true>;
+            else ak = f4 <= 1 ? fuse_cells_kernel<1, 1, false, true> : f4 <= 2 ? fuse_cells_kernel<1, 2, false, true> : f4 <= 4 ? fuse_cells_kernel<1, 4, false, true>
+                    : f4 <= 7 ? fuse_cells_kernel<1, 7, false, true> : fuse_cells_kernel<1, 8, false, true>;
+            if (stamps && kind == 1 && f4 == 7) ak = fuse_cells_kernel<1, 7, true, true>;
+            {
+                std::lock_guard<std::mutex> lock(mu4);
+                size_t &have = granted4[(const void *)ak];
+                if (have < clds) {
+                    MF_HIP_CHECK(hipFuncSetAttribute((const void *)ak, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+                    have = clds;
+                }
+            }
+            hipLaunchKernelGGL(ak, dim3(blocks_cells), dim3(CELLS_NT), clds, st, S);   // aggregated entries: returns at once unless the call's format is FMT_AGG
+            MF_LAUNCH_CHECK("fuse_cells_kernel<AGG>");
+        }
     }
     if (single) {
         SingleParams S;

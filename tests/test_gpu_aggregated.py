@@ -1,0 +1,109 @@
+"""Aggregated entries (bucket_agg_kernel -> fuse_cells_kernel<AGG>): the corners of a block's points are summed per
+(tile, frame, voxel, class) in LDS before they are written - collision compaction for real scenes.
+
+Every case is compared with the oracle loop of layer.update() calls (base_projection_layer.py:282-343 ->
+projection.py:233-351); mf_fuse_last_mode proves that the aggregated path ran.  Covered: a room trajectory (tens of
+corners per entry), unrelated frames (hardly any collisions: most corners lose their slot or are alone in it), ones
+features, iw = 1, a map that is not zero, invalid class ids, tiles whose cells need several windows, more than 64
+frames per call, stage / commit pairs, and bit-identical repetition."""
+import pytest
+import torch
+
+from conftest import assert_map_close, last_fuse_mode
+from test_gpu_cells import layers, run_both, sparse_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def room_frames(n, H, W, C, seed):
+    from mass_amd.episodes import room_trajectory
+    tr = room_trajectory(n, H, W, seed=seed, num_classes=C)
+    return {k: tr[k] for k in ("position", "yaw", "elevation", "depth", "semantic")}
+
+
+@pytest.mark.parametrize("scene", ["room", "unrelated"])
+@pytest.mark.parametrize("kind,C,iw", [("label", 54, 0.5), ("label", 5, 1.0), ("ones", 1, 0.5), ("ones", 1, 1.0)])
+def test_aggregated_entries_match_the_oracle(device, monkeypatch, scene, kind, C, iw):
+    """Two batches of 16 frames onto a 64^3 map, the second one onto what the first left."""
+    from mass_amd import _lib
+    monkeypatch.setenv("MF_FORMAT", "aggregated")
+    H, W, M, n = 60, 80, 64, 16
+    lay, ref = layers(device, kind, C, H, W, M, 0.1, iw=iw)
+    fr = room_frames(2 * n, H, W, C, seed=3) if scene == "room" else sparse_frames(2 * n, H, W, C, seed=7)
+    for sl in (slice(0, n), slice(n, 2 * n)):
+        run_both(lay, ref, fr, sl, kind, C)
+        assert last_fuse_mode(lay, n) == _lib.MODE_CELLS_AGG
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"{scene} {kind} C={C} iw={iw} aggregated")
+
+
+def test_probe_sends_a_room_to_the_aggregated_path_when_it_is_on(device, monkeypatch):
+    from mass_amd import _lib
+    monkeypatch.delenv("MF_FORMAT", raising=False)
+    H, W, M, C, n = 60, 80, 64, 9, 12
+    lay, ref = layers(device, "label", C, H, W, M, 0.1)
+    fr = room_frames(n, H, W, C, seed=2)
+    run_both(lay, ref, fr, slice(0, n), "label", C)
+    assert last_fuse_mode(lay, n) in (_lib.MODE_CELLS_AGG, _lib.MODE_DENSE)     # (MF_AGG / the library's default decide which)
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="room, the probe's choice")
+
+
+def test_invalid_class_ids_nonzero_map_and_repetition(device, monkeypatch):
+    """Class ids >= C count as all-zero feature rows (they still add to W and S2); the map starts out non-zero; a
+    second run on a fresh copy of the same map gives the same bits (all sums are integers)."""
+    from mass_amd import _lib
+    monkeypatch.setenv("MF_FORMAT", "aggregated")
+    H, W, M, C, n = 60, 80, 64, 7, 10
+    fr = room_frames(n, H, W, C + 3, seed=5)                     # ids up to C + 2
+    g = torch.Generator().manual_seed(9)
+    init = torch.rand(M, M, M, C, generator=g) * (torch.rand(M, M, M, 1, generator=g) < 0.3)
+    outs = []
+    for rep in range(2):
+        lay, ref = layers(device, "label", C, H, W, M, 0.1)
+        lay.data.copy_(init)
+        ref.data.copy_(init)
+        if rep == 0:
+            run_both(lay, ref, fr, slice(0, n), "label", C)
+            assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="invalid ids onto a non-zero map, aggregated")
+        else:
+            batch = {k: fr[k][:n] for k in ("position", "yaw", "elevation", "depth", "semantic")}
+            lay.update_batch(batch, sequential=True, validate=False)
+        assert last_fuse_mode(lay, n) == _lib.MODE_CELLS_AGG
+        outs.append(lay.data.clone())
+    assert torch.equal(outs[0], outs[1]), "aggregated entries: two runs differ"
+
+
+def test_many_frames_and_windows(device, monkeypatch):
+    """150 frames in one call (64-frame windows of the masks) of a camera that keeps looking at the same wall: the tiles
+    of that wall need more cells than fit and take their frames in several windows."""
+    from mass_amd import _lib
+    monkeypatch.setenv("MF_FORMAT", "aggregated")
+    H, W, M, C, n = 48, 64, 64, 5, 150
+    lay, ref = layers(device, "label", C, H, W, M, 0.1)
+    fr = room_frames(n, H, W, C, seed=11)
+    run_both(lay, ref, fr, slice(0, n), "label", C)
+    assert last_fuse_mode(lay, n) == _lib.MODE_CELLS_AGG
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="150 room frames, aggregated")
+
+
+def test_stage_commit_pairs(device, monkeypatch):
+    """The pipelined issue path (stage on a side stream, commit alone) with aggregated entries."""
+    from mass_amd import _lib
+    from mass_amd.utils.projection import FusePipeline
+    monkeypatch.setenv("MF_FORMAT", "aggregated")
+    H, W, M, C, n, per = 60, 80, 64, 9, 24, 8
+    lay, ref = layers(device, "label", C, H, W, M, 0.1)
+    fr = room_frames(n, H, W, C, seed=4)
+    pipe = FusePipeline(device)
+    depth, sem = fr["depth"].to(device).reshape(n, H, W), fr["semantic"].to(device)
+    for a in range(0, n, per):
+        sl = slice(a, a + per)
+        poses = lay._poses(fr["position"][sl], fr["yaw"][sl], fr["elevation"][sl])
+        pipe.submit(lay.bins_x, lay.bins_y, lay.bins_z, lay.rays, poses, depth[sl], sem[sl], lay.data,
+                    interpolation_weight=lay.interpolation_weight, sequential=True)
+    pipe.flush()
+    assert [last_fuse_mode(lay, per, ws) for ws in pipe.ws] == [_lib.MODE_CELLS_AGG, _lib.MODE_CELLS_AGG]
+    for t in range(n):
+        feats = torch.nn.functional.one_hot(fr["semantic"][t].long(), C).float()
+        ref.update(dict(position=fr["position"][t], yaw=fr["yaw"][t], elevation=fr["elevation"][t],
+                        depth=fr["depth"][t], features=feats))
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="stage / commit pairs, aggregated")
