@@ -730,17 +730,14 @@ __device__ __forceinline__ unsigned long long to_fixed(float w, int fx_c)
 // (atomicMin, order independent).  Corners whose key won their slot are summed there and leave as ONE entry; a
 // corner that lost is written as an entry of its own.  Both kernels see the same keys, hence the same winners.
 constexpr int AGG_BITS = 10, AGG_SLOTS = 1 << AGG_BITS;
-constexpr unsigned long long AGG_EMPTY = ~0ull;
+#ifndef AGG_ABL
+#define AGG_ABL 0
+#endif
 constexpr int AGG_FW = 32, AGG_FS = 55;            // fraction bits of an entry's W / S2
 #ifndef AGG_DEFAULT
 #define AGG_DEFAULT 0
 #endif
 
-__device__ __forceinline__ int agg_slot(unsigned long long k)
-{
-    const uint32_t x = ((uint32_t)k ^ ((uint32_t)(k >> 32) * 0x85ebca6bu) ^ ((uint32_t)(k >> 15) * 0x27d4eb2fu)) * 2654435761u;
-    return (int)(x >> (32 - AGG_BITS));
-}
 __device__ __forceinline__ uint4 make_agg_entry(unsigned hdr, unsigned long long W, unsigned long long S)
 {
     uint4 e;
@@ -753,23 +750,40 @@ __device__ __forceinline__ uint4 make_agg_entry(unsigned hdr, unsigned long long
 __device__ __forceinline__ unsigned long long agg_W(const uint4 &e) { return (unsigned long long)e.y | ((unsigned long long)(e.x >> 23) << 32); }
 __device__ __forceinline__ unsigned long long agg_S(const uint4 &e) { return (unsigned long long)e.z | ((unsigned long long)e.w << 32); }
 
+// position i of lane l <- position i ^ r: neighbouring pixels of a real scene have the SAME footprint, and in corner order
+// the lanes of one LDS atomic would all hit the same few words (same-address LDS atomics are served one lane at a time:
+// measured, 1.0 ms of the first version's 1.0 ms).  With the corners rotated per lane, lanes with the same footprint add
+// DIFFERENT corners in the same instruction.
+template <class T>
+__device__ __forceinline__ void xor_permute8(T (&a)[8], unsigned r)
+{
+#pragma unroll
+    for (int b = 1; b < 8; b <<= 1) {
+        const bool sw = r & b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (!(i & b)) { const T x = a[i], y = a[i | b]; a[i] = sw ? y : x; a[i | b] = sw ? x : y; }
+    }
+}
+
 template <bool SCATTER>
 __global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
 {
-    __shared__ unsigned long long akey[AGG_SLOTS];
+    __shared__ uint32_t akey[AGG_SLOTS];
     __shared__ unsigned long long aW[SCATTER ? AGG_SLOTS : 1], aS[SCATTER ? AGG_SLOTS : 1];
     __shared__ uint32_t hkey[HS];
     __shared__ int hcnt[HS];
     __shared__ int hfill;
     if (entry_format(P.ticket, P.meta, P.fmt_force) != FMT_AGG) return;        // count_kernel / scatter_kernel take the call (uniform)
     for (int s = threadIdx.x; s < AGG_SLOTS; s += BIN_THREADS) {
-        akey[s] = AGG_EMPTY;
+        akey[s] = EMPTY;
         if (SCATTER) { aW[s] = 0ull; aS[s] = 0ull; }
     }
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
     if (threadIdx.x == 0) hfill = 0;
     __syncthreads();
     const long long idx = point_index<0>(P, BIN_THREADS);
+    const int group = P.G == 1 ? 0 : (int)blockIdx.y;
     Point pt;
     bool ok = false;
     if (!SCATTER) {
@@ -792,68 +806,99 @@ __global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
             const unsigned rm = 0x3fffffffu;
             pt.k0 = r.x & 1023; pt.k1 = (r.x >> 10) & 1023; pt.k2 = (r.x >> 20) & 1023;
             pt.r0 = __uint_as_float(r.y & rm); pt.r1 = __uint_as_float(r.z & rm); pt.r2 = __uint_as_float(r.w & rm);
-            pt.group = P.G == 1 ? 0 : (int)blockIdx.y;
         }
     }
-    // the eight corners: key = (bucket of the corner's tile, class id, voxel inside the tile), slot, weight
-    unsigned long long ck[8];
+    // The eight corners.  key = tile << 15 | class << 7 | voxel inside the tile (the frame is the block's: 32 bits do for
+    // maps of up to 2^17 tiles, the host offers the format to no other; a class id outside [0, C) is kept as C <= 64, so no
+    // key is all ones = EMPTY).
+    uint32_t ck[8];
+    int cs[8];
     float cw[8];
-    unsigned lose = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { ck[c] = EMPTY; cs[c] = 0; cw[c] = 0.0f; }
     if (ok) {
         uint32_t label = 0u;
         if (P.feat_kind != MF_FEAT_ONES) {
             const Pix px = patch_pixel(P);
             label = read_label(P.feat, P.feat_kind, feature_pixel((int)blockIdx.y, px.y, px.x, P.fh, P.fw, P.rep_y, P.rep_x));
         }
-        const unsigned low = (label > 255u ? 255u : label) << 7;
-        TileKeys K;
-        point_keys8(P, pt, K);
-        const float w0[2] = {K.a0.wlo, K.a0.whi}, w1[2] = {K.a1.wlo, K.a1.whi}, w2[2] = {K.a2.wlo, K.a2.whi};
-        const unsigned x0[2] = {(unsigned)(K.a0.lo & 3) << 5, (unsigned)(K.a0.hi & 3) << 5};
-        const unsigned x1[2] = {(unsigned)(K.a1.lo & 3) << 3, (unsigned)(K.a1.hi & 3) << 3};
-        const unsigned x2[2] = {(unsigned)(K.a2.lo & 7), (unsigned)(K.a2.hi & 7)};
+        const uint32_t cls = label > (uint32_t)P.C ? (uint32_t)P.C : label;
+        const AxisFoot a0 = axis_foot(pt.k0, pt.r0, P.size0), a1 = axis_foot(pt.k1, pt.r1, P.size1), a2 = axis_foot(pt.k2, pt.r2, P.size2);
+        const float w0[2] = {a0.wlo, a0.whi}, w1[2] = {a1.wlo, a1.whi}, w2[2] = {a2.wlo, a2.whi};
+        // per axis: the corner's tile coordinate (pre-multiplied) and its voxel bits inside the tile (4 x 4 x 8 tiles)
+        const uint32_t t0[2] = {(uint32_t)(a0.lo >> 2) * (uint32_t)(P.nt1 * P.nt2), (uint32_t)(a0.hi >> 2) * (uint32_t)(P.nt1 * P.nt2)};
+        const uint32_t t1[2] = {(uint32_t)(a1.lo >> 2) * (uint32_t)P.nt2, (uint32_t)(a1.hi >> 2) * (uint32_t)P.nt2};
+        const uint32_t t2[2] = {(uint32_t)(a2.lo >> 3), (uint32_t)(a2.hi >> 3)};
+        const uint32_t x0[2] = {(uint32_t)(a0.lo & 3) << 5, (uint32_t)(a0.hi & 3) << 5};
+        const uint32_t x1[2] = {(uint32_t)(a1.lo & 3) << 3, (uint32_t)(a1.hi & 3) << 3};
+        const uint32_t x2[2] = {(uint32_t)(a2.lo & 7), (uint32_t)(a2.hi & 7)};
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int ca = c >> 2, cb = (c >> 1) & 1, cd = c & 1;
-            // (w0 * w1) * w2 + 1e-9, the reference's product order (projection.py:319-323); corner c lies in the tile of key position c & straddle
+            // (w0 * w1) * w2 + 1e-9, the reference's product order (projection.py:319-323)
             cw[c] = 1e-9f + (w0[ca] * w1[cb]) * w2[cd];
-            ck[c] = ((unsigned long long)K.key[c & K.straddle] << 15) | low | x0[ca] | x1[cb] | x2[cd];
-            atomicMin(&akey[agg_slot(ck[c])], ck[c]);
+            const uint32_t tile = t0[ca] + t1[cb] + t2[cd], v = x0[ca] | x1[cb] | x2[cd];
+            ck[c] = (tile << 15) | (cls << 7) | v;
         }
+    }
+    {
+        const unsigned lane = threadIdx.x & 63u, rot = (lane ^ (lane >> 3)) & 7u;
+        xor_permute8(ck, rot);
+        if (SCATTER) xor_permute8(cw, rot);
+    }
+    // (a plain multiplicative hash: slots made of the voxel bits and a few hash bits of (tile, class) were measured too - the
+    // tiles along a wall use the same voxels of their tiles, and when two of them share the hash bits one loses everything)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cs[c] = (int)((ck[c] * 2654435761u) >> (32 - AGG_BITS));
+    // a slot goes to the smallest key that hashes to it (a slot that already holds a key this small is left alone: plain
+    // reads of one word are broadcast, atomics on it are not)
+    {
+        uint32_t cur[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cur[c] = *(volatile uint32_t *)&akey[cs[c]];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (AGG_ABL < 3 && ck[c] < cur[c]) atomicMin(&akey[cs[c]], ck[c]);
     }
     __syncthreads();
-    int lslot[8], lrank[8];
+    // a corner whose key holds its slot is summed there; one that lost is an entry of its own (slot in the bucket from the
+    // global counter directly: rare in a real scene)
+    unsigned lose = 0u;
     {
-        const bool open = hash_open(&hfill);
-        if (ok) {
+        uint32_t cur[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int s = agg_slot(ck[c]);
-                lslot[c] = -1; lrank[c] = 0;
-                if (akey[s] == ck[c]) {
-                    if (SCATTER) {
-                        atomicAdd(&aW[s], to_fixed(cw[c], 182 - AGG_FW));
-                        atomicAdd(&aS[s], to_fixed(cw[c] * cw[c], 182 - AGG_FS));
-                    }
-                } else {
-                    lose |= 1u << c;
-                    const uint32_t tk = (uint32_t)(ck[c] >> 15);
-                    lslot[c] = hash_insert(hkey, hcnt, &hfill, tk, lrank[c], open, 1);
-                    if (!SCATTER && lslot[c] < 0) atomicAdd(&P.cursor[tk], 1);
+        for (int c = 0; c < 8; ++c) cur[c] = akey[cs[c]];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (ck[c] == EMPTY) continue;
+            if (cur[c] == ck[c]) {
+                if (SCATTER && AGG_ABL < 2) {
+                    atomicAdd(&aW[cs[c]], to_fixed(cw[c], 182 - AGG_FW));
+                    atomicAdd(&aS[cs[c]], to_fixed(cw[c] * cw[c], 182 - AGG_FS));
                 }
-            }
+            } else lose |= 1u << c;
         }
     }
-    // one entry per claimed slot
+    const unsigned fbits = (unsigned)group << 15;
+    if (lose && AGG_ABL < 1) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (lose & (1u << c)) {
+                const int pos = atomicAdd(&P.cursor[(ck[c] >> 15) * (uint32_t)P.G + (uint32_t)group], 1);
+                if (SCATTER)
+                    P.rec[pos] = make_agg_entry((ck[c] & 0x7fffu) | fbits, to_fixed(cw[c], 182 - AGG_FW), to_fixed(cw[c] * cw[c], 182 - AGG_FS));
+            }
+    }
+    // one entry per claimed slot: the slots of a bucket are ranked through the block's table of (tile, frame) buckets
     int sslot[AGG_SLOTS / BIN_THREADS], srank[AGG_SLOTS / BIN_THREADS];
     {
         const bool open = hash_open(&hfill);
 #pragma unroll
         for (int i = 0; i < AGG_SLOTS / BIN_THREADS; ++i) {
-            const unsigned long long k = akey[threadIdx.x + BIN_THREADS * i];
+            const uint32_t k = akey[threadIdx.x + BIN_THREADS * i];
             sslot[i] = -1; srank[i] = 0;
-            if (k != AGG_EMPTY) {
-                const uint32_t tk = (uint32_t)(k >> 15);
+            if (k != EMPTY) {
+                const uint32_t tk = (k >> 15) * (uint32_t)P.G + (uint32_t)group;
                 sslot[i] = hash_insert(hkey, hcnt, &hfill, tk, srank[i], open, 1);
                 if (!SCATTER && sslot[i] < 0) atomicAdd(&P.cursor[tk], 1);
             }
@@ -868,25 +913,14 @@ __global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS)
         if (hkey[s] != EMPTY) hcnt[s] = atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
     __syncthreads();
-    const unsigned fbits = (unsigned)(P.G == 1 ? 0 : (int)blockIdx.y) << 15;
 #pragma unroll
     for (int i = 0; i < AGG_SLOTS / BIN_THREADS; ++i) {
         const int s = threadIdx.x + BIN_THREADS * i;
-        const unsigned long long k = akey[s];
-        if (k != AGG_EMPTY) {
-            const uint32_t tk = (uint32_t)(k >> 15);
-            const int pos = sslot[i] >= 0 ? hcnt[sslot[i]] + srank[i] : atomicAdd(&P.cursor[tk], 1);
-            P.rec[pos] = make_agg_entry(((unsigned)k & 0x7fffu) | fbits, aW[s], aS[s]);
+        const uint32_t k = akey[s];
+        if (k != EMPTY) {
+            const int pos = sslot[i] >= 0 ? hcnt[sslot[i]] + srank[i] : atomicAdd(&P.cursor[(k >> 15) * (uint32_t)P.G + (uint32_t)group], 1);
+            P.rec[pos] = make_agg_entry((k & 0x7fffu) | fbits, aW[s], aS[s]);
         }
-    }
-    if (lose) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (lose & (1u << c)) {
-                const uint32_t tk = (uint32_t)(ck[c] >> 15);
-                const int pos = lslot[c] >= 0 ? hcnt[lslot[c]] + lrank[c] : atomicAdd(&P.cursor[tk], 1);
-                P.rec[pos] = make_agg_entry(((unsigned)ck[c] & 0x7fffu) | fbits, to_fixed(cw[c], 182 - AGG_FW), to_fixed(cw[c] * cw[c], 182 - AGG_FS));
-            }
     }
 }
 
@@ -3360,6 +3394,8 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
     static const bool agg_on = env_int("MF_AGG", 0, 1, AGG_DEFAULT) != 0;
     const int fmt_env_force = !fmt_env ? (agg_on ? 4 : 0) : fmt_env[0] == 'c' ? 1 : fmt_env[0] == 'r' ? 2 : fmt_env[0] == 'a' ? 3 : (agg_on ? 4 : 0);
     P.fmt_force = !P.meta ? 0 : (!use_cells || dense_forced) ? 2 : cells_forced ? 1 : fmt_env_force;
+    // (bucket_agg_kernel's keys hold the tile in 17 bits: larger maps keep records for real scenes)
+    if (P.n_tiles > (1 << 17) && P.fmt_force >= 3) P.fmt_force = P.fmt_force == 3 ? 2 : 0;
     const bool agg_offered = P.meta && (P.fmt_force == 3 || P.fmt_force == 4);
     // fixed-point fraction bits of the W / S2 sums: the per-voxel, per-frame sum of weights is
     // below (points per group) * (1 + 1e-9), and must stay below 2^63
