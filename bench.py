@@ -201,7 +201,7 @@ def cpu_baseline(frames, per_rep, reps=3):
     return rec, lay, n
 
 
-MODE_NAMES = {0: "fuse_tiles_kernel", 2: "fuse_dense_kernel", 3: "fuse_cells_kernel"}
+MODE_NAMES = {0: "fuse_tiles_kernel", 2: "fuse_dense_kernel", 3: "fuse_cells_kernel", 4: "fuse_cells_kernel<aggregated entries>"}
 
 
 def last_mode(lay, n_frames, ws=None):

@@ -730,12 +730,13 @@ __device__ __forceinline__ unsigned long long to_fixed(float w, int fx_c)
 // (atomicMin, order independent).  Corners whose key won their slot are summed there and leave as ONE entry; a
 // corner that lost is written as an entry of its own.  Both kernels see the same keys, hence the same winners.
 constexpr int AGG_BITS = 10, AGG_SLOTS = 1 << AGG_BITS;
+constexpr int AGG2_BITS = 8, AGG2_SLOTS = 1 << AGG2_BITS;           // the second table, for the keys that lost in the first
 #ifndef AGG_ABL
 #define AGG_ABL 0
 #endif
 constexpr int AGG_FW = 32, AGG_FS = 55;            // fraction bits of an entry's W / S2
 #ifndef AGG_DEFAULT
-#define AGG_DEFAULT 0
+#define AGG_DEFAULT 1
 #endif
 
 __device__ __forceinline__ uint4 make_agg_entry(unsigned hdr, unsigned long long W, unsigned long long S)
@@ -769,8 +770,8 @@ __device__ __forceinline__ void xor_permute8(T (&a)[8], unsigned r)
 template <bool SCATTER>
 __global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
 {
-    __shared__ uint32_t akey[AGG_SLOTS];
-    __shared__ unsigned long long aW[SCATTER ? AGG_SLOTS : 1], aS[SCATTER ? AGG_SLOTS : 1];
+    __shared__ uint32_t akey[AGG_SLOTS], bkey[AGG2_SLOTS];
+    __shared__ unsigned long long aW[SCATTER ? AGG_SLOTS : 1], aS[SCATTER ? AGG_SLOTS : 1], bW[SCATTER ? AGG2_SLOTS : 1], bS[SCATTER ? AGG2_SLOTS : 1];
     __shared__ uint32_t hkey[HS];
     __shared__ int hcnt[HS];
     __shared__ int hfill;
@@ -778,6 +779,10 @@ __global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
     for (int s = threadIdx.x; s < AGG_SLOTS; s += BIN_THREADS) {
         akey[s] = EMPTY;
         if (SCATTER) { aW[s] = 0ull; aS[s] = 0ull; }
+    }
+    for (int s = threadIdx.x; s < AGG2_SLOTS; s += BIN_THREADS) {
+        bkey[s] = EMPTY;
+        if (SCATTER) { bW[s] = 0ull; bS[s] = 0ull; }
     }
     for (int s = threadIdx.x; s < HS; s += BIN_THREADS) { hkey[s] = EMPTY; hcnt[s] = 0; }
     if (threadIdx.x == 0) hfill = 0;
@@ -861,8 +866,10 @@ __global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
             if (AGG_ABL < 3 && ck[c] < cur[c]) atomicMin(&akey[cs[c]], ck[c]);
     }
     __syncthreads();
-    // a corner whose key holds its slot is summed there; one that lost is an entry of its own (slot in the bucket from the
-    // global counter directly: rare in a real scene)
+    // A corner whose key holds its slot is summed there.  One that lost (~5 % of a real scene's corners: ~100 distinct keys
+    // on 1,024 slots) tries a second, small table the same way; what loses there too is an entry of its own, its place in
+    // the bucket from the global counter directly (rare: without the second table these atomics - all corners of a losing
+    // key on the same counter - were a third of both kernels' time).
     unsigned lose = 0u;
     {
         uint32_t cur[8];
@@ -876,26 +883,40 @@ __global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
                     atomicAdd(&aW[cs[c]], to_fixed(cw[c], 182 - AGG_FW));
                     atomicAdd(&aS[cs[c]], to_fixed(cw[c] * cw[c], 182 - AGG_FS));
                 }
-            } else lose |= 1u << c;
+            } else {
+                lose |= 1u << c;
+                atomicMin(&bkey[(ck[c] * 0x85ebca6bu) >> (32 - AGG2_BITS)], ck[c]);
+            }
         }
     }
+    __syncthreads();
     const unsigned fbits = (unsigned)group << 15;
     if (lose && AGG_ABL < 1) {
 #pragma unroll
         for (int c = 0; c < 8; ++c)
             if (lose & (1u << c)) {
-                const int pos = atomicAdd(&P.cursor[(ck[c] >> 15) * (uint32_t)P.G + (uint32_t)group], 1);
-                if (SCATTER)
-                    P.rec[pos] = make_agg_entry((ck[c] & 0x7fffu) | fbits, to_fixed(cw[c], 182 - AGG_FW), to_fixed(cw[c] * cw[c], 182 - AGG_FS));
+                const int s2 = (int)((ck[c] * 0x85ebca6bu) >> (32 - AGG2_BITS));
+                if (bkey[s2] == ck[c]) {
+                    if (SCATTER) {
+                        atomicAdd(&bW[s2], to_fixed(cw[c], 182 - AGG_FW));
+                        atomicAdd(&bS[s2], to_fixed(cw[c] * cw[c], 182 - AGG_FS));
+                    }
+                } else {
+                    const int pos = atomicAdd(&P.cursor[(ck[c] >> 15) * (uint32_t)P.G + (uint32_t)group], 1);
+                    if (SCATTER)
+                        P.rec[pos] = make_agg_entry((ck[c] & 0x7fffu) | fbits, to_fixed(cw[c], 182 - AGG_FW), to_fixed(cw[c] * cw[c], 182 - AGG_FS));
+                }
             }
     }
     // one entry per claimed slot: the slots of a bucket are ranked through the block's table of (tile, frame) buckets
-    int sslot[AGG_SLOTS / BIN_THREADS], srank[AGG_SLOTS / BIN_THREADS];
+    constexpr int NS = (AGG_SLOTS + AGG2_SLOTS + BIN_THREADS - 1) / BIN_THREADS;
+    auto slot_key = [&](int s) { return s < AGG_SLOTS ? akey[s] : s < AGG_SLOTS + AGG2_SLOTS ? bkey[s - AGG_SLOTS] : EMPTY; };
+    int sslot[NS], srank[NS];
     {
         const bool open = hash_open(&hfill);
 #pragma unroll
-        for (int i = 0; i < AGG_SLOTS / BIN_THREADS; ++i) {
-            const uint32_t k = akey[threadIdx.x + BIN_THREADS * i];
+        for (int i = 0; i < NS; ++i) {
+            const uint32_t k = slot_key(threadIdx.x + BIN_THREADS * i);
             sslot[i] = -1; srank[i] = 0;
             if (k != EMPTY) {
                 const uint32_t tk = (k >> 15) * (uint32_t)P.G + (uint32_t)group;
@@ -914,12 +935,13 @@ __global__ __launch_bounds__(BIN_THREADS) void bucket_agg_kernel(FuseParams P)
         if (hkey[s] != EMPTY) hcnt[s] = atomicAdd(&P.cursor[hkey[s]], hcnt[s]);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < AGG_SLOTS / BIN_THREADS; ++i) {
+    for (int i = 0; i < NS; ++i) {
         const int s = threadIdx.x + BIN_THREADS * i;
-        const uint32_t k = akey[s];
+        const uint32_t k = slot_key(s);
         if (k != EMPTY) {
             const int pos = sslot[i] >= 0 ? hcnt[sslot[i]] + srank[i] : atomicAdd(&P.cursor[(k >> 15) * (uint32_t)P.G + (uint32_t)group], 1);
-            P.rec[pos] = make_agg_entry((k & 0x7fffu) | fbits, aW[s], aS[s]);
+            P.rec[pos] = s < AGG_SLOTS ? make_agg_entry((k & 0x7fffu) | fbits, aW[s], aS[s])
+                                       : make_agg_entry((k & 0x7fffu) | fbits, bW[s - AGG_SLOTS], bS[s - AGG_SLOTS]);
         }
     }
 }

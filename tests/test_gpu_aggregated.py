@@ -36,14 +36,14 @@ def test_aggregated_entries_match_the_oracle(device, monkeypatch, scene, kind, C
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"{scene} {kind} C={C} iw={iw} aggregated")
 
 
-def test_probe_sends_a_room_to_the_aggregated_path_when_it_is_on(device, monkeypatch):
+def test_probe_sends_a_room_to_the_aggregated_path(device, monkeypatch):
     from mass_amd import _lib
     monkeypatch.delenv("MF_FORMAT", raising=False)
     H, W, M, C, n = 60, 80, 64, 9, 12
     lay, ref = layers(device, "label", C, H, W, M, 0.1)
     fr = room_frames(n, H, W, C, seed=2)
     run_both(lay, ref, fr, slice(0, n), "label", C)
-    assert last_fuse_mode(lay, n) in (_lib.MODE_CELLS_AGG, _lib.MODE_DENSE)     # (MF_AGG / the library's default decide which)
+    assert last_fuse_mode(lay, n) == _lib.MODE_CELLS_AGG
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="room, the probe's choice")
 
 

@@ -113,7 +113,7 @@ def test_points_on_voxel_centres_and_faces(device):
               semantic=torch.randint(0, C, (n, H, W), generator=g).to(torch.uint8))
     fr["position"][:, 0] = 0.0625 * torch.arange(n)
     run_both(lay, ref, fr, slice(0, n), "label", C)
-    assert last_fuse_mode(lay, n) in (_lib.MODE_CELLS, _lib.MODE_DENSE)
+    assert last_fuse_mode(lay, n) in (_lib.MODE_CELLS, _lib.MODE_DENSE, _lib.MODE_CELLS_AGG)
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="centres and faces")
 
 
@@ -144,12 +144,13 @@ def test_blend_weight_above_one_goes_to_the_float_tile_kernel(device):
 
 
 @pytest.mark.parametrize("scene", ["unrelated", "room"])
-@pytest.mark.parametrize("fmt", ["contributions", "records", None])
+@pytest.mark.parametrize("fmt", ["contributions", "records", "aggregated", None])
 def test_either_entry_format_gives_the_oracle_map(device, monkeypatch, scene, fmt):
-    """The probe's choice of the tile-local entry format (contributions -> fuse_cells_kernel, 16-byte records ->
-    fuse_dense_kernel) only decides the speed: forced either way, or left to the probe (None), a batch of unrelated
-    frames and a room trajectory both come out within tolerance of the oracle; left alone, the probe sends the
-    unrelated frames to the cells kernel and the room to the dense one."""
+    """The probe's choice of the tile-local entry format (contributions -> fuse_cells_kernel, aggregated entries ->
+    fuse_cells_kernel<AGG>; 16-byte records -> fuse_dense_kernel when forced or with MF_AGG=0) only decides the speed:
+    forced any way, or left to the probe (None), a batch of unrelated frames and a room trajectory both come out within
+    tolerance of the oracle; left alone, the probe sends the unrelated frames to contributions and the room to
+    aggregated entries."""
     from mass_amd import _lib
     from mass_amd.episodes import room_trajectory
     if fmt is None:
@@ -165,8 +166,8 @@ def test_either_entry_format_gives_the_oracle_map(device, monkeypatch, scene, fm
         fr = {k: tr[k] for k in ("position", "yaw", "elevation", "depth", "semantic")}
     run_both(lay, ref, fr, slice(0, n), "label", C)
     mode = last_fuse_mode(lay, n)
-    want = {"contributions": _lib.MODE_CELLS, "records": _lib.MODE_DENSE,
-            None: _lib.MODE_CELLS if scene == "unrelated" else _lib.MODE_DENSE}[fmt]
+    want = {"contributions": _lib.MODE_CELLS, "records": _lib.MODE_DENSE, "aggregated": _lib.MODE_CELLS_AGG,
+            None: _lib.MODE_CELLS if scene == "unrelated" else _lib.MODE_CELLS_AGG}[fmt]
     assert mode == want
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"{scene} frames as {fmt or 'the probe chose'}")
 

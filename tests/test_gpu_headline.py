@@ -43,8 +43,9 @@ def test_headline_launch_64_frames_vs_oracle(device):
     assert occupied > 900_000 * min(n, 8)
 
 
+@pytest.mark.parametrize("fmt", ["records", None])
 @pytest.mark.parametrize("kind,iw,batches", [("label", 0.5, 2), ("label", 1.0, 1), ("ones", 0.5, 2)])
-def test_room_batches_fullsize_dense_kernel_vs_oracle(device, kind, iw, batches):
+def test_room_batches_fullsize_dense_kernel_vs_oracle(device, monkeypatch, kind, iw, batches, fmt):
     """The kernel behind the room-batch rate at ITS shape: 480x640 -> 256^3 x 54, sequential
     batches of 34 room frames through fuse_dense_kernel (two chunks of 32 + 2 frames per tile, the second
     batch blends onto the first), each against the oracle loop; also iw = 1 and the occupancy (ones) map."""
@@ -53,6 +54,11 @@ def test_room_batches_fullsize_dense_kernel_vs_oracle(device, kind, iw, batches)
     from mass_amd.episodes import room_trajectory
     from mass_amd.nn.applications.occupancy_projection_layer import OccupancyProjectionLayer
     from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    # fmt None: the probe's choice for a real scene, aggregated entries -> fuse_cells_kernel<AGG>; "records": fuse_dense_kernel
+    if fmt is None:
+        monkeypatch.delenv("MF_FORMAT", raising=False)
+    else:
+        monkeypatch.setenv("MF_FORMAT", fmt)
     n = 34
     tr = room_trajectory(batches * n, H, W, seed=2)
     kw = dict(KW, interpolation_weight=iw)
@@ -69,7 +75,7 @@ def test_room_batches_fullsize_dense_kernel_vs_oracle(device, kind, iw, batches)
         if kind == "label":
             batch["semantic"] = tr["semantic"][sl].to(device)
         lay.update_batch(batch, sequential=True)
-        assert last_fuse_mode(lay, n) == _lib.MODE_DENSE
+        assert last_fuse_mode(lay, n) == (_lib.MODE_DENSE if fmt else _lib.MODE_CELLS_AGG)
         for t in range(sl.start, sl.stop):
             feats = (torch.nn.functional.one_hot(tr["semantic"][t].long(), C).float() if kind == "label"
                      else torch.ones(H, W, 1))
