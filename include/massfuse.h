@@ -158,12 +158,14 @@ MF_API size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int
  * semantic_projection_layer.py:203-214 / occupancy_projection_layer.py:159-161).
  * Updates grid->map in place.  n_frames <= 256 per call.
  * The workspace needs no initialisation and holds nothing between calls.
- * Sequential frames of class ids / ones are bucketed on 4x4x8 map tiles and fused by one of two
- * all-integer tile kernels, picked on the device from the call's point density (fuse_cells_kernel
- * for unrelated / sparse frames, fuse_dense_kernel for real scenes); everything else (dense fp32
- * features, blend weights outside [0, 1], odd map shapes) takes fuse_tiles_kernel.  The choice is a
- * function of the call's arguments and data only: the library keeps no state between calls, and the
- * integer kernels give run-to-run identical bits. */
+ * Sequential frames of class ids / ones are bucketed on 4x4x8 map tiles in a tile-local entry format
+ * picked on the device from a sample of the call's points - unrelated / sparse frames: one
+ * contribution per corner of a point's footprint; real scenes: the corners of a pixel patch summed
+ * per (voxel, class) before they are written (aggregated entries) - and fused by the all-integer
+ * fuse_cells_kernel (fuse_dense_kernel over point records for maps of more than 2^17 tiles);
+ * everything else (dense fp32 features, blend weights outside [0, 1], odd map shapes) takes
+ * fuse_tiles_kernel.  The choice is a function of the call's arguments and data only: the library
+ * keeps no state between calls, and the integer kernels give run-to-run identical bits. */
 MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
                    int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -258,7 +260,8 @@ MF_API int mf_profile_read(int32_t call, float *ms /* [5] host */);
 
 /* Which tile kernel took the most recent multi-frame call of class-id / ones frames issued with
  * this workspace (same grid, n_points and n_groups as that call): 0 fuse_tiles_kernel,
- * 2 fuse_dense_kernel, 3 fuse_cells_kernel; < 0 on error.  Reads one word of the workspace back and
+ * 2 fuse_dense_kernel, 3 fuse_cells_kernel (contributions), 4 fuse_cells_kernel over aggregated
+ * entries (real scenes); < 0 on error.  Reads one word of the workspace back and
  * WAITS for `stream`.  Used by the tests to prove which path ran. */
 MF_API int mf_fuse_last_mode(const mf_grid *grid, int64_t n_points, int32_t n_groups, const void *workspace,
                              void *stream);

@@ -23,14 +23,17 @@
 //                  format has no room for it) of every (pixel, tile) pair into its bucket slot
 //                  (slot = bucket base + LDS-local rank);
 //   4. tile kernel, one of
-//        fuse_cells_kernel   sequential frames of class ids / ones, sparse (a batch of unrelated frames): all
-//                  frames of a 4 x 4 x 8 tile at once through compact (voxel, frame) cells, integer sums
-//                  only, three 256-thread workgroups per CU (see there);
-//        fuse_dense_kernel   the same feature kinds, real scenes: everything accumulated as integers on
-//                  4 x 4 x 8 tiles, suffix form of the unrolled blend (see there);
-//                  (both read tile-local CONTRIBUTIONS, make_contribution: scatter_kernel expands a point into
-//                  one 8-byte entry per corner of its footprint, in the bucket of the corner's tile; tile_list_kernel
-//                  picks one of the two from the call's own point density: no state is kept between calls)
+//        fuse_cells_kernel   sequential frames of class ids / ones: all frames of a 4 x 4 x 8 tile at once through
+//                  compact (voxel, frame) cells, integer sums only, three 256-thread workgroups per CU (see there).
+//                  A batch of unrelated frames reaches it as CONTRIBUTIONS (make_contribution: scatter_kernel expands a
+//                  point into one 8-byte entry per corner of its footprint, in the bucket of the corner's tile), a real
+//                  scene as AGGREGATED entries (bucket_agg_kernel: a block's corners summed per (tile, frame, voxel,
+//                  class) in LDS before anything is written - collision compaction; fuse_cells_kernel<AGG>);
+//        fuse_dense_kernel   the same feature kinds, real scenes as 16-byte tile-local records (MF_AGG=0, maps of more
+//                  than 2^17 tiles, merged batches): everything accumulated as integers on 4 x 4 x 8 tiles, suffix form
+//                  of the unrolled blend (see there);
+//                  (probe_kernel samples the call's points and picks the entry format, tile_list_kernel the tile kernel
+//                  that goes with it: a function of the call's data alone, no state is kept between calls)
 //        fuse_tiles_kernel   dense fp32 features, blend weights outside [0, 1], any tile shape: persistent
 //                  workgroups walk the tile list (ticket counter; the next tile's ticket, id,
 //                  offsets and first records are fetched one tile ahead).  The tile's old map
@@ -52,6 +55,7 @@
 // Tuning / diagnostics, all off by default and range-checked (env_int): MF_TILE="s0 s1 s2 threads [gc]"
 // overrides the tile shape of fuse_tiles_kernel, MF_DENSE=0 keeps calls off the 4 x 4 x 8 integer kernels,
 // MF_DENSE_FORCE / MF_CELLS_FORCE give every eligible call to that kernel, MF_CELLS=0 keeps the cells kernel out,
+// MF_FORMAT=contributions / records / aggregated overrides the probe's entry format per call, MF_AGG=0 keeps real scenes on records,
 // MF_DENSE_GC / MF_DENSE_NT / MF_CELLS_PER_CU size them, MF_BLOCKS caps the workgroups,
 // MF_STAMPS=1 prints the share of each phase of the tile kernel (dev builds of bench runs).
 #include <cstdlib>
