@@ -411,7 +411,13 @@ class FusePipeline:
             check(_lib.MF_ERR_INVALID)
         slot = self.k & 1
         main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)                       # the inputs were produced on the caller's stream
+        inputs = torch.cuda.Event()
+        inputs.record(main)                               # the inputs were produced on the caller's stream
+        # The batch staged by the previous submit is committed FIRST: the staging call below waits on the host for its
+        # probe (a few words read back: which entry format the frames ask for), i.e. for everything the side stream waits
+        # for, and the caller's stream must have its work queued by then.
+        self._commit()
+        self.side.wait_event(inputs)
         if self.committed[slot] is not None:
             self.side.wait_event(self.committed[slot])    # the workspace is free once its last commit is done
         with torch.cuda.stream(self.side):
@@ -419,9 +425,7 @@ class FusePipeline:
             check(lib.mf_fuse_frames_stage(g, fr, float(interpolation_weight), mode, wptr, wbytes,
                                            _lib.c_void_p(self.side.cuda_stream)))
             self.staged[slot].record(self.side)
-        mine = (slot, g, fr, float(interpolation_weight), mode, wptr, wbytes, keep, fm)
-        self._commit()                                    # the batch staged by the previous submit
-        self.pending = mine
+        self.pending = (slot, g, fr, float(interpolation_weight), mode, wptr, wbytes, keep, fm)
         self.k += 1
 
     def _commit(self):

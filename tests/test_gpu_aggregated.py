@@ -107,3 +107,51 @@ def test_stage_commit_pairs(device, monkeypatch):
         ref.update(dict(position=fr["position"][t], yaw=fr["yaw"][t], elevation=fr["elevation"][t],
                         depth=fr["depth"][t], features=feats))
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="stage / commit pairs, aggregated")
+
+
+PROCESS_CASE = r"""
+import sys, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+from conftest import assert_map_close, last_fuse_mode
+from test_gpu_cells import layers, sparse_frames, run_both
+from test_gpu_aggregated import room_frames
+from mass_amd import _lib
+from mass_amd.utils.projection import FusePipeline
+dev = torch.device("cuda:0")
+H, W, M, C, n = 60, 80, 64, 9, 12
+for scene, want in (("room", %(room)d), ("unrelated", _lib.MODE_CELLS)):
+    lay, ref = layers(dev, "label", C, H, W, M, 0.1)
+    fr = room_frames(n, H, W, C, seed=2) if scene == "room" else sparse_frames(n, H, W, C, seed=41)
+    run_both(lay, ref, fr, slice(0, n), "label", C)
+    assert last_fuse_mode(lay, n) == want, (scene, last_fuse_mode(lay, n), want)
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=scene)
+    # stage / commit pairs: the commit takes the verdict of its staging call (or, without the read-back, launches every variant)
+    lay2, _ = layers(dev, "label", C, H, W, M, 0.1)
+    pipe = FusePipeline(dev)
+    depth, sem = fr["depth"].to(dev).reshape(n, H, W), fr["semantic"].to(dev)
+    for a in range(0, n, 4):
+        sl = slice(a, a + 4)
+        pipe.submit(lay2.bins_x, lay2.bins_y, lay2.bins_z, lay2.rays, lay2._poses(fr["position"][sl], fr["yaw"][sl], fr["elevation"][sl]),
+                    depth[sl], sem[sl], lay2.data, interpolation_weight=lay2.interpolation_weight, sequential=True)
+    pipe.flush()
+    assert [last_fuse_mode(lay2, 4, ws) for ws in pipe.ws] == [want, want]
+    assert_map_close(lay2.data.cpu().numpy(), ref.data.numpy(), what=scene + ", stage / commit pairs")
+print("PROBE_OK")
+"""
+
+
+@pytest.mark.parametrize("env,room_mode", [({"MF_PROBE_SYNC": "0"}, 2), ({"MF_AGG": "0"}, 2), ({}, 4)])
+def test_probe_read_back_switches(env, room_mode):
+    """MF_PROBE_SYNC=0: the host does not wait for the probe - every variant of contributions / records is launched and
+    the probe picks on the device (aggregated entries are not offered: a room goes to fuse_dense_kernel); MF_AGG=0: read
+    back, records for real scenes; default: read back, aggregated entries.  Fresh processes (read once per process); plain
+    calls and stage / commit pairs, rooms and unrelated frames, each against the oracle."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ, PYTHONPATH=ROOT, **env)
+    e.pop("MF_FORMAT", None)
+    out = subprocess.run([sys.executable, "-c", PROCESS_CASE % dict(root=ROOT, room=room_mode)], env=e, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and "PROBE_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
