@@ -165,7 +165,11 @@ MF_API size_t mf_fuse_workspace_bytes(const mf_grid *grid, int64_t n_points, int
  * fuse_cells_kernel (fuse_dense_kernel over point records for maps of more than 2^17 tiles);
  * everything else (dense fp32 features, blend weights outside [0, 1], odd map shapes) takes
  * fuse_tiles_kernel.  The choice is a function of the call's arguments and data only: the library
- * keeps no state between calls, and the integer kernels give run-to-run identical bits. */
+ * keeps no state between calls, and the integer kernels give run-to-run identical bits.
+ * Such a call (several sequential frames of class ids / ones) reads its probe's verdict back on
+ * the host - it WAITS for `stream`'s earlier work and ~30 us - and launches only the kernels of the
+ * chosen format; MF_PROBE_SYNC=0 (environment, read once) launches every variant instead and lets
+ * the device pick (no wait; aggregated entries are then not used). */
 MF_API int mf_fuse_frames(const mf_grid *grid, const mf_frames *frames, float interpolation_weight,
                    int32_t mode, void *workspace, size_t workspace_bytes, void *stream);
 
