@@ -225,6 +225,14 @@ MF_API int mf_column_occupied(const float *map, int32_t size0, int32_t size1, in
 MF_API int mf_amax_z(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels, float *out,
                      void *stream);
 
+/* The counters an episode reports about a map, in one pass: out[0] = voxels with a non-zero
+ * channel (`(data != 0).any(-1).sum()`), out[1] = sum of |map| in units of 2^-24 (an exact integer
+ * sum, each term truncated: the same bits whatever the order; divide by 2^24 for `data.abs().sum()`).
+ * out: 2 words, scratch: 2 * MF_MAP_STATS_PARTS words, both device memory (no initialisation). */
+#define MF_MAP_STATS_PARTS 2048
+MF_API int mf_map_stats(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels,
+                        uint64_t *out, uint64_t *scratch, void *stream);
+
 /* ---- instance extraction, SemanticProjectionLayer.find ---------- */
 
 /* cv2.findContours(RETR_LIST) + cv2.boundingRect (semantic_projection_layer.py:323-328) on

@@ -22,6 +22,7 @@ METRIC_L2, METRIC_L2_GEMM, METRIC_COSINE = 0, 1, 2
 MAX_FRAMES_PER_CALL = 256
 ABI_VERSION = 5
 MODE_TILES, MODE_DENSE, MODE_CELLS, MODE_CELLS_AGG = 0, 2, 3, 4
+MAP_STATS_PARTS = 2048        # MF_MAP_STATS_PARTS
 MAX_MAPS_PER_CALL = 4          # mf_fuse_frame_maps          # mf_fuse_last_mode
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
@@ -81,6 +82,7 @@ SIGNATURES = {
     "mf_column_occupied": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
                                           c_void_p, c_void_p]),
     "mf_amax_z": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "mf_map_stats": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "mf_contour_boxes": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32]),
     "mf_roi_moments": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),

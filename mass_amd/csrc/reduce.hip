@@ -6,6 +6,9 @@
 //       (this kernel produces the `any` mask; the 2-D max_pool2d padding of :220-221 stays
 //        in torch on the tiny [H, W] image)
 //   mf_amax_z           /root/reference/agent.py:330-331, 391-392:  data.amax(dim=2)
+//   mf_map_stats        the counters an episode reports about its maps (occupied voxels, sum |map|): what
+//       `(data != 0).any(-1).sum()` and `data.abs().sum()` give, in ONE pass over the map (bench.py --workload episode:
+//       the torch expressions move the 3.6 GB map five times and build a 3.6 GB temporary)
 //
 // A (y, x) column of the map is one contiguous run of D*C floats, so both kernels give a
 // workgroup one column and read it with consecutive lanes on consecutive floats.
@@ -68,6 +71,74 @@ __global__ __launch_bounds__(RT) void amax_z_kernel(const float *__restrict__ ma
     }
 }
 
+// Per workgroup: voxels of its columns with a non-zero channel, and sum |x| as a 64-bit integer in units of 2^-24 (an exact,
+// order-independent sum: the same bits whatever the number of workgroups or ranks).  part[2 b] / part[2 b + 1].
+__global__ __launch_bounds__(RT) void map_stats_kernel(const float *__restrict__ map, int n_cols, int D, int C, unsigned magicC,
+                                                        int vec4, unsigned long long *part)
+{
+    extern __shared__ int flag[];            // [D]
+    __shared__ unsigned long long wsum[RT / 64];
+    __shared__ int wcnt[RT / 64];
+    const int n = D * C;
+    unsigned long long acc = 0ull;
+    int cnt = 0;
+    auto take = [&](float x, unsigned e) {
+        x = fabsf(x);
+        if (x != 0.0f) {
+            flag[magicC ? __umulhi(e, magicC) : e] = 1;                       // voxel e / C (benign race: every writer stores 1)
+            acc += (unsigned long long)(fminf(x, 5.0e11f) * 16777216.0f);
+        }
+    };
+    for (int col = blockIdx.x; col < n_cols; col += gridDim.x) {
+        for (int z = threadIdx.x; z < D; z += RT) flag[z] = 0;
+        __syncthreads();
+        const float *src = map + (size_t)col * n;
+        if (vec4) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            for (int i = threadIdx.x; i < n / 4; i += RT) {
+                const float4 v = s4[i];
+                const unsigned e = 4u * i;
+                take(v.x, e); take(v.y, e + 1); take(v.z, e + 2); take(v.w, e + 3);
+            }
+        } else {
+            for (int e = threadIdx.x; e < n; e += RT) take(src[e], (unsigned)e);
+        }
+        __syncthreads();
+        for (int z = threadIdx.x; z < D; z += RT) cnt += flag[z];
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o, 64);
+        acc += (unsigned long long)__shfl_down((long long)acc, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = acc; wcnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0ull, c = 0ull;
+        for (int w = 0; w < RT / 64; ++w) { a += wsum[w]; c += (unsigned long long)wcnt[w]; }
+        part[2 * blockIdx.x] = c;
+        part[2 * blockIdx.x + 1] = a;
+    }
+}
+
+__global__ __launch_bounds__(RT) void map_stats_sum_kernel(const unsigned long long *__restrict__ part, int n_parts, unsigned long long *out)
+{
+    __shared__ unsigned long long sh[2][RT / 64];
+    unsigned long long c = 0ull, a = 0ull;
+    for (int i = threadIdx.x; i < n_parts; i += RT) { c += part[2 * i]; a += part[2 * i + 1]; }
+    for (int o = 32; o > 0; o >>= 1) {
+        c += (unsigned long long)__shfl_down((long long)c, o, 64);
+        a += (unsigned long long)__shfl_down((long long)a, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = c; sh[1][threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = 0ull; a = 0ull;
+        for (int w = 0; w < RT / 64; ++w) { c += sh[0][w]; a += sh[1][w]; }
+        out[0] = c; out[1] = a;
+    }
+}
+
 }  // namespace mf
 
 using namespace mf;
@@ -100,6 +171,26 @@ int mf_amax_z(const float *map, int32_t size0, int32_t size1, int32_t size2, int
     hipLaunchKernelGGL(amax_z_kernel, dim3((unsigned)(size0 * size1)), dim3(RT), 0, (hipStream_t)stream, map, size2,
                        channels, out);
     MF_LAUNCH_CHECK("amax_z_kernel");
+    return MF_OK;
+}
+
+int mf_map_stats(const float *map, int32_t size0, int32_t size1, int32_t size2, int32_t channels, uint64_t *out,
+                 uint64_t *scratch, void *stream)
+{
+    if (!map || !out || !scratch) return fail(MF_ERR_INVALID, "NULL pointer");
+    if (size0 < 1 || size1 < 1 || size2 < 1 || channels < 1) return fail(MF_ERR_INVALID, "bad map shape");
+    if ((long long)size2 * channels > 0x7fffffffLL / 4) return fail(MF_ERR_INVALID, "column of %d x %d floats too long", size2, channels);
+    if ((size_t)size2 * 4 > 60 * 1024) return fail(MF_ERR_INVALID, "map depth %d too large for the statistics kernel", size2);
+    const int n_cols = size0 * size1;
+    const int blocks = n_cols < MF_MAP_STATS_PARTS ? n_cols : MF_MAP_STATS_PARTS;
+    const unsigned magicC = channels == 1 ? 0u : (unsigned)(((1ull << 32) + channels - 1) / channels);
+    const int vec4 = ((uintptr_t)map % 16 == 0) && (((long long)size2 * channels) % 4 == 0);
+    hipLaunchKernelGGL(map_stats_kernel, dim3((unsigned)blocks), dim3(RT), (size_t)size2 * 4, (hipStream_t)stream, map, n_cols,
+                       size2, channels, magicC, vec4, (unsigned long long *)scratch);
+    MF_LAUNCH_CHECK("map_stats_kernel");
+    hipLaunchKernelGGL(map_stats_sum_kernel, dim3(1), dim3(RT), 0, (hipStream_t)stream, (const unsigned long long *)scratch, blocks,
+                       (unsigned long long *)out);
+    MF_LAUNCH_CHECK("map_stats_sum_kernel");
     return MF_OK;
 }
 

@@ -145,6 +145,7 @@ def run_episode(prepared, layers, batch=64):
     (= per-frame layer.update() calls), then predict_scene_differences over the object classes.
     Returns the episode's counters (what the ranks all-reduce at the end of a multi-GPU run)."""
     from mass_amd.utils.experimentation import predict_scene_differences
+    from mass_amd.utils.reductions import map_stats
     n_frames, frames = prepared["n_frames"], 0
     for tr, lay in zip(prepared["phases"], layers):
         lay.reset()
@@ -157,6 +158,8 @@ def run_episode(prepared, layers, batch=64):
     obj, goals0, goals1 = predict_scene_differences(layers[0], layers[1], None, None, set(), list(OBJECT_CLASSES),
                                                     confidence_threshold=0.0, contour_padding=0, distance_threshold=0.5)
     shift = float((goals1[0] - goals0[0]).norm()) if goals0 else 0.0
+    # the maps' counters (occupied voxels, sum |map|) in one pass per map (mf_map_stats: the torch expressions
+    # `(data != 0).any(-1).sum()` and `data.abs().sum()` move a 3.6 GB map five times)
+    stats = [map_stats(l.data) for l in layers]
     return dict(episodes=1, frames=frames, moved_found=int(obj == MOVED_CLASS), n_matches=len(goals0), shift_m=shift,
-                occupied_voxels=float(sum(int((l.data != 0).any(-1).sum()) for l in layers)),
-                map_abs_sum=float(sum(float(l.data.abs().sum(dtype=torch.float64)) for l in layers)))
+                occupied_voxels=float(sum(s[0] for s in stats)), map_abs_sum=float(sum(s[1] for s in stats)))

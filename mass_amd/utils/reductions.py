@@ -4,11 +4,12 @@ as single-pass HIP kernels:
     navigable_area   /root/reference/mass/navigation_policy.py:208-221 (body; the method itself
                      belongs to NavigationPolicy, which is out of scope)
     amax_z           /root/reference/agent.py:330-331, 391-392   data.amax(dim=2)
+    map_stats        occupied voxels and sum |map| of a map in one pass (the counters of bench.py's episode workload)
 """
 import torch
 import torch.nn.functional as functional
 
-from mass_amd._lib import lib, check, ptr, require_device, current_stream
+from mass_amd._lib import lib, check, ptr, require_device, current_stream, MAP_STATS_PARTS
 
 
 def _map4(data):
@@ -46,3 +47,16 @@ def amax_z(data):
     out = torch.empty(H, W, C, dtype=torch.float32, device=data.device)
     check(lib.mf_amax_z(ptr(data), H, W, D, C, ptr(out), current_stream(data.device)))
     return out
+
+
+def map_stats(data):
+    """(occupied voxels, sum |data|): `int((data != 0).any(-1).sum())` and `float(data.abs().sum())` in one pass over the
+    map.  The sum is an exact integer sum of the terms truncated to 2^-24 (the same bits whatever the order).  Waits for
+    the stream (16 bytes are read back)."""
+    data = _map4(data)
+    H, W, D, C = data.shape
+    out = torch.empty(2, dtype=torch.int64, device=data.device)
+    scratch = torch.empty(2 * MAP_STATS_PARTS, dtype=torch.int64, device=data.device)
+    check(lib.mf_map_stats(ptr(data), H, W, D, C, ptr(out), ptr(scratch), current_stream(data.device)))
+    occupied, fx = out.tolist()
+    return int(occupied), fx / 16777216.0

@@ -38,3 +38,21 @@ def test_against_torch_cpu(device, shape):
     for sl, thr, pad in ((None, 0.0, 3), (slice(4, 32), 0.0, 1), (slice(1, 5), 0.3 * shape[3] ** 0.5, 0)):
         assert torch.equal(navigable_area(d, pad, sl, thr).cpu(), ref_navigable(data, pad, sl, thr))
     assert not column_occupied(torch.zeros_like(d)).any()
+
+
+@pytest.mark.parametrize("shape", [(24, 20, 32, 54), (7, 5, 9, 3), (16, 16, 8, 1), (5, 6, 256, 54)])
+def test_map_stats_matches_the_torch_expressions(device, shape):
+    """mf_map_stats: `(data != 0).any(-1).sum()` exactly, `data.abs().sum()` up to the 2^-24 each term is truncated to;
+    the same bits on a second run (integer sums); columns that are no multiple of four floats; an all-zero map."""
+    from mass_amd.utils.reductions import map_stats
+    g = torch.Generator().manual_seed(sum(shape))
+    data = (torch.rand(shape, generator=g) - 0.3) * (torch.rand(shape[:3] + (1,), generator=g) < 0.2)
+    data[0, 0, 0, :] = 0.0
+    data[1, 1, 1, -1] = 1e-9                       # a voxel whose only non-zero entry is tiny
+    d = data.to(device)
+    occ, s = map_stats(d)
+    assert occ == int((data != 0).any(-1).sum())
+    want = float(data.abs().sum(dtype=torch.float64))
+    assert abs(s - want) <= data.numel() * 2.0 ** -24 + 1e-9 * want
+    assert map_stats(d) == (occ, s)
+    assert map_stats(torch.zeros(shape, device=device)) == (0, 0.0)
