@@ -109,6 +109,31 @@ def test_stage_commit_pairs(device, monkeypatch):
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="stage / commit pairs, aggregated")
 
 
+def test_out_of_range_class_id_calls_the_batch_off(device, monkeypatch):
+    """A class id outside [0, C) anywhere in a batch of room frames (the reference's one_hot raises before anything is
+    written, semantic_projection_layer.py:203-209): bucket_agg_kernel<false> sees it like count_kernel does - the call raises
+    (validate=True) or reports at check_labels (validate="defer"), the map is left as it was, and the layer keeps working."""
+    from mass_amd import _lib
+    monkeypatch.delenv("MF_FORMAT", raising=False)
+    H, W, M, C, n = 60, 80, 64, 9, 8
+    lay, ref = layers(device, "label", C, H, W, M, 0.1)
+    fr = room_frames(2 * n, H, W, C, seed=6)
+    run_both(lay, ref, fr, slice(0, n), "label", C)
+    assert last_fuse_mode(lay, n) == _lib.MODE_CELLS_AGG
+    before = lay.data.clone()
+    bad = {k: fr[k][n:2 * n].clone() for k in ("position", "yaw", "elevation", "depth", "semantic")}
+    bad["semantic"][3, H // 2, W // 3] = C + 2
+    with pytest.raises(RuntimeError, match="Class values"):
+        lay.update_batch(bad, sequential=True)
+    assert torch.equal(lay.data, before)
+    lay.update_batch(bad, sequential=True, validate="defer")
+    with pytest.raises(RuntimeError, match="Class values"):
+        lay.check_labels()
+    assert torch.equal(lay.data, before)
+    run_both(lay, ref, fr, slice(n, 2 * n), "label", C)           # the good frames of the same slice
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="after the batches that were called off")
+
+
 PROCESS_CASE = r"""
 import sys, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
