@@ -134,6 +134,48 @@ def test_out_of_range_class_id_calls_the_batch_off(device, monkeypatch):
     assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what="after the batches that were called off")
 
 
+def test_two_host_threads_batch_calls(device, monkeypatch):
+    """Two host threads, each fusing batches into its own layer on its own stream - one a room (aggregated entries), one
+    unrelated frames (contributions): the probe's read-back buffer is per thread, the verdicts kept for commits are per
+    workspace."""
+    import threading
+    from mass_amd import _lib
+    monkeypatch.delenv("MF_FORMAT", raising=False)
+    H, W, M, C, n = 60, 80, 64, 9, 12
+    cases = [("room", room_frames(n, H, W, C, seed=8), _lib.MODE_CELLS_AGG), ("unrelated", sparse_frames(n, H, W, C, seed=9), _lib.MODE_CELLS)]
+    pairs = [layers(device, "label", C, H, W, M, 0.1) for _ in cases]
+    errors, modes = [], [None, None]
+
+    def work(i):
+        try:
+            lay, fr = pairs[i][0], cases[i][1]
+            with torch.cuda.stream(torch.cuda.Stream(device)):
+                for rep in range(3):
+                    lay.reset()
+                    for a in range(0, n, 4):
+                        lay.update_batch({k: fr[k][a:a + 4] for k in ("position", "yaw", "elevation", "depth", "semantic")},
+                                         sequential=True, validate=False)
+                torch.cuda.current_stream().synchronize()
+                modes[i] = last_fuse_mode(lay, 4)
+        except Exception as exc:                         # noqa: BLE001 (reported below)
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, (name, fr, want) in enumerate(cases):
+        assert modes[i] == want
+        ref = pairs[i][1]
+        for t in range(n):
+            feats = torch.nn.functional.one_hot(fr["semantic"][t].long(), C).float()
+            ref.update(dict(position=fr["position"][t], yaw=fr["yaw"][t], elevation=fr["elevation"][t], depth=fr["depth"][t],
+                            features=feats))
+        assert_map_close(pairs[i][0].data.cpu().numpy(), ref.data.numpy(), what=f"{name}, thread {i}")
+
+
 PROCESS_CASE = r"""
 import sys, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
