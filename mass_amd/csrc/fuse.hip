@@ -2126,7 +2126,6 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 }
 
 constexpr int CELLS_FX = 31;              // fraction bits of the deltas
-constexpr int CELLS_CR = 4;               // contributions per thread kept in registers (fetched a tile ahead)
 
 // A 64-bit fixed-point sum as a float: two 32-bit conversions and one multiply-add (the compiler's correctly rounded
 // u64 -> f32 is a dozen instructions; the double rounding here is far below the 1e-4 the map is held to).
@@ -2135,8 +2134,11 @@ __device__ __forceinline__ float u64_to_float(unsigned long long x)
     return __builtin_fmaf((float)(unsigned)(x >> 32), 4294967296.0f, (float)(unsigned)x);
 }
 
-template <int KIND, int F4, bool STAMPS = false, bool AGG = false>   // F4: float4s per thread and tile (ceil(32 C / 256)); AGG: aggregated 16-byte entries (bucket_agg_kernel)
-__global__ __launch_bounds__(256, 3) void fuse_cells_kernel(TileParams P)
+#ifndef CELLS_CR_COMMIT
+#define CELLS_CR_COMMIT 8
+#endif
+template <int KIND, int F4, bool STAMPS = false, bool AGG = false, int CELLS_CR = 4>   // F4: float4s per thread and tile (ceil(32 C / 256)); AGG: aggregated 16-byte entries (bucket_agg_kernel); CELLS_CR: entries per thread kept in registers
+__global__ __launch_bounds__(256, CELLS_CR > 4 ? 2 : 3) void fuse_cells_kernel(TileParams P)
 {
     typedef typename std::conditional<AGG, uint4, uint2>::type Ent;
     extern __shared__ float smem[];
@@ -3643,6 +3645,13 @@ static int run_pipeline(FuseParams &P, const mf_grid *grid, void *workspace, siz
         if (kind == 0) ck = fuse_cells_kernel<0, 1>;
         else ck = f4 <= 1 ? fuse_cells_kernel<1, 1> : f4 <= 2 ? fuse_cells_kernel<1, 2> : f4 <= 4 ? fuse_cells_kernel<1, 4> : f4 <= 7 ? fuse_cells_kernel<1, 7> : fuse_cells_kernel<1, 8>;
         if (stamps && kind == 1 && f4 == 7) ck = fuse_cells_kernel<1, 7, true>;      // (dev: the headline shape)
+        // A commit on its own runs two workgroups per CU (beside the next batch's bucketing kernels): registers for 2,048
+        // instead of 1,024 of a tile's contributions, i.e. 80 % instead of 60 % of the headline's tiles never stream an entry a
+        // second and third time.  Five alternating runs of 60 steps: tile kernel 2.08-2.15 -> 2.00-2.04 ms as timed, step
+        // 2.54 -> 2.49 ms; with three workgroups per CU (the call that has the chip to itself) 161 registers are too many
+        // (1.80-1.87 -> 1.88 ms): that call keeps 1,024.  MF_CELLS_CR8=0: off (dev).
+        static const bool cr8 = env_int("MF_CELLS_CR8", 0, 1, 1) != 0;
+        if (cr8 && phase != 3 && kind == 1 && f4 == 7 && !stamps) ck = fuse_cells_kernel<1, 7, false, false, CELLS_CR_COMMIT>;
         const size_t clds = cells_lds_bytes(P.C, cells_cap);
         static std::mutex mu4;
         static std::unordered_map<const void *, size_t> granted4;
