@@ -35,8 +35,8 @@ python3 tools/pmc_summary.py $outb/sq mf:: > $outb/sq_summary.txt
 echo "room done"
 # summarise here (the raw traces are too bulky to travel back), keep the summaries only
 mkdir -p gpurun_out/prof_summary
-MF_PROFILE_KERNEL='mf::fuse_cells_kernel<1, 7, false, false>' MF_PROFILE_OUT=gpurun_out/prof_summary python3 tools/summarize_profiles.py ${1:-r03} distA_sequential_b64 > gpurun_out/prof_summary/summary.log 2>&1 || { tail -5 gpurun_out/prof_summary/summary.log; exit 1; }
-MF_PROFILE_SRC=$outb MF_PROFILE_KERNEL='mf::fuse_cells_kernel<1, 7, false, true>' MF_PROFILE_OUT=gpurun_out/prof_summary python3 tools/summarize_profiles.py ${1:-r03}_room room_sequential_b64 > gpurun_out/prof_summary/summary_room.log 2>&1 || { tail -5 gpurun_out/prof_summary/summary_room.log; exit 1; }
+MF_PROFILE_KERNEL='mf::fuse_cells_kernel<1, 7, false, false, 8>' MF_PROFILE_OUT=gpurun_out/prof_summary python3 tools/summarize_profiles.py ${1:-r03} distA_sequential_b64 > gpurun_out/prof_summary/summary.log 2>&1 || { tail -5 gpurun_out/prof_summary/summary.log; exit 1; }
+MF_PROFILE_SRC=$outb MF_PROFILE_KERNEL='mf::fuse_cells_kernel<1, 7, false, true, 4>' MF_PROFILE_OUT=gpurun_out/prof_summary python3 tools/summarize_profiles.py ${1:-r03}_room room_sequential_b64 > gpurun_out/prof_summary/summary_room.log 2>&1 || { tail -5 gpurun_out/prof_summary/summary_room.log; exit 1; }
 cp $outb/bench_under_kt.json gpurun_out/prof_summary/${1:-r03}_room_bench_under_rocprof.json
 cp $outb/sq_summary.txt gpurun_out/prof_summary/${1:-r03}_room_sq_counters.txt
 rm -rf $outb

@@ -89,7 +89,8 @@ for k in sorted(set(fetch) | set(write)):
         h, m = tcc[k].get("TCC_HIT_sum", 0.0), tcc[k].get("TCC_MISS_sum", 0.0)
         e["L2_hit_rate"] = h / (h + m) if h + m else None
     summary[k] = e
-    if "unproject_bin" not in k:
+    # (the step's total: the tile kernel that did the work, not the other instantiations that ran in the untimed warm-up)
+    if "unproject_bin" not in k and not (k.startswith("mf::fuse_") and not k.startswith(fuse_kernel)):
         total += hbm
 summary["_pipeline_total_hbm_bytes_per_step"] = total
 with open(os.path.join(out_dir, f"{tag}_hbm_counters.json"), "w") as f:
