@@ -176,6 +176,28 @@ def test_two_host_threads_batch_calls(device, monkeypatch):
         assert_map_close(pairs[i][0].data.cpu().numpy(), ref.data.numpy(), what=f"{name}, thread {i}")
 
 
+@pytest.mark.parametrize("C,my,mx", [(24, 64, 64), (60, 64, 64), (54, 30, 34), (3, 22, 26)])
+def test_other_channel_counts_and_maps_that_are_no_multiple_of_the_tile(device, monkeypatch, C, my, mx):
+    """Every float4-slot instantiation of fuse_cells_kernel<AGG> (C <= 8, 32, 56, 64) and maps whose height / width are no
+    multiples of four (border tiles: rows outside the map are neither read nor written), onto a map that is not zero."""
+    from oracle import massref as orc
+    from mass_amd import _lib
+    from mass_amd.nn.applications.semantic_projection_layer import SemanticProjectionLayer
+    monkeypatch.setenv("MF_FORMAT", "aggregated")
+    H, W, n = 60, 80, 10
+    kw = dict(camera_height=H, camera_width=W, map_height=my, map_width=mx, map_depth=32, grid_resolution=0.1, interpolation_weight=0.5)
+    lay = SemanticProjectionLayer(feature_size=C, **kw).train().to(device)
+    ref = orc.RefProjectionLayer(feature_size=C, **kw)
+    g = torch.Generator().manual_seed(200 + C + my)
+    init = torch.rand(my, mx, 32, C, generator=g) * (torch.rand(my, mx, 32, 1, generator=g) < 0.3)
+    lay.data.copy_(init)
+    ref.data.copy_(init)
+    fr = sparse_frames(n, H, W, C, seed=C + mx, dmax=2.5, spread=0.2) if C == 3 else room_frames(n, H, W, C, seed=C)
+    run_both(lay, ref, fr, slice(0, n), "label", C)
+    assert last_fuse_mode(lay, n) == _lib.MODE_CELLS_AGG
+    assert_map_close(lay.data.cpu().numpy(), ref.data.numpy(), what=f"aggregated, C={C} map {my}x{mx}x32")
+
+
 PROCESS_CASE = r"""
 import sys, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
