@@ -89,3 +89,15 @@ def test_pose_cache_is_replaced_and_read_as_one_entry():
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+
+def test_whole_map_reductions_refuse_cpu_tensors():
+    """amax_z / column_occupied / map_stats have no CPU path either: a map that is not on a HIP device raises, a map of
+    the wrong rank or dtype is refused before anything is launched."""
+    import pytest
+    import torch
+    from mass_amd.utils import reductions
+    cpu_map = torch.zeros(4, 4, 8, 3)
+    for fn in (reductions.amax_z, reductions.column_occupied, reductions.map_stats):
+        with pytest.raises(RuntimeError, match="HIP device"):
+            fn(cpu_map)
