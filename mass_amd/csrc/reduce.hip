@@ -44,12 +44,49 @@ __global__ __launch_bounds__(RT) void column_occupied_kernel(const float *__rest
 }
 
 // out[col][c] = max_z map[col][z][c]
-__global__ __launch_bounds__(RT) void amax_z_kernel(const float *__restrict__ map, int D, int C, float *out)
+// vec4: the column is read as float4s.  Thread t of the first P4 * (RT / P4) threads strides the column by S4 = P4 * (RT / P4)
+// float4s, P4 = C / gcd(C, 4) float4s being the period after which a float4 starts on the same channel again: its four lanes
+// see four fixed channels (4 t + k) mod C all the way down, and the threads that share them meet in LDS at the end
+// (16-byte loads: 0.78 -> ~0.6 ms on the 3.6 GB semantic map).
+__global__ __launch_bounds__(RT) void amax_z_kernel(const float *__restrict__ map, int D, int C, int P4, float *out)
 {
-    __shared__ float part[RT];
+    __shared__ float part[4 * RT];
     const float *src = map + (size_t)blockIdx.x * D * C;
     float *dst = out + (size_t)blockIdx.x * C;
-    if (C <= RT) {
+    if (P4 > 0) {
+        const int rep = RT / P4, S4 = P4 * rep, n4 = (D * C) >> 2;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if ((int)threadIdx.x < S4) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            for (int i = threadIdx.x; i < n4; i += S4) {
+                const float4 v = s4[i];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        reinterpret_cast<float4 *>(part)[threadIdx.x] = m;
+        __syncthreads();
+        // the threads t0, t0 + P4, ... share their four channels: folded by thread t0 first ...
+        if ((int)threadIdx.x < P4) {
+            float4 r = reinterpret_cast<float4 *>(part)[threadIdx.x];
+            for (int j = 1; j < rep; ++j) {
+                const float4 v = reinterpret_cast<float4 *>(part)[threadIdx.x + j * P4];
+                r.x = fmaxf(r.x, v.x); r.y = fmaxf(r.y, v.y); r.z = fmaxf(r.z, v.z); r.w = fmaxf(r.w, v.w);
+            }
+            reinterpret_cast<float4 *>(part)[threadIdx.x] = r;
+        }
+        __syncthreads();
+        // ... then channel c collects the lanes (c - first channel of t0's float4) mod C < 4 over the P4 threads
+        if ((int)threadIdx.x < C) {
+            const int c = threadIdx.x;
+            float r = -INFINITY;
+            for (int t0 = 0; t0 < P4; ++t0) {
+                const int c0 = (4 * t0) % C;
+                const int k = c - c0 < 0 ? c - c0 + C : c - c0;
+                if (k < 4) r = fmaxf(r, part[4 * t0 + k]);
+            }
+            dst[c] = r;
+        }
+    } else if (C <= RT) {
         // threads t < S = C * (RT / C) stride the column by S, so a thread always sees channel t % C
         const int rep = RT / C, S = C * rep, n = D * C;
         float m = -INFINITY;
@@ -168,8 +205,12 @@ int mf_amax_z(const float *map, int32_t size0, int32_t size1, int32_t size2, int
 {
     if (!map || !out) return fail(MF_ERR_INVALID, "NULL pointer");
     if (size0 < 1 || size1 < 1 || size2 < 1 || channels < 1) return fail(MF_ERR_INVALID, "bad map shape");
+    // float4 path: columns that start on 16 bytes, a period of at most RT float4s, and channels that fit one pass of the fold
+    int g = channels % 4 == 0 ? 4 : channels % 2 == 0 ? 2 : 1;
+    int P4 = channels / g;
+    if (((uintptr_t)map % 16 != 0) || (((long long)size2 * channels) % 4 != 0) || P4 > RT || channels > RT || channels < 4) P4 = 0;
     hipLaunchKernelGGL(amax_z_kernel, dim3((unsigned)(size0 * size1)), dim3(RT), 0, (hipStream_t)stream, map, size2,
-                       channels, out);
+                       channels, P4, out);
     MF_LAUNCH_CHECK("amax_z_kernel");
     return MF_OK;
 }

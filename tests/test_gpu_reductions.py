@@ -56,3 +56,19 @@ def test_map_stats_matches_the_torch_expressions(device, shape):
     assert abs(s - want) <= data.numel() * 2.0 ** -24 + 1e-9 * want
     assert map_stats(d) == (occ, s)
     assert map_stats(torch.zeros(shape, device=device)) == (0, 0.0)
+
+
+@pytest.mark.parametrize("shape", [(9, 7, 256, 54), (6, 5, 8, 5), (4, 4, 12, 8), (5, 3, 7, 6), (3, 3, 16, 64), (2, 3, 4, 255), (8, 8, 32, 4)])
+def test_amax_z_float4_path_and_its_fallbacks(device, shape):
+    """mf_amax_z reads a column as float4s when it starts on 16 bytes and its length is a multiple of four floats (each
+    thread then sees four fixed channels: the period is C / gcd(C, 4) float4s), else float by float: channel counts with
+    every gcd, a column length that is no multiple of four, negative values, a map view at an odd offset."""
+    from mass_amd.utils.reductions import amax_z
+    g = torch.Generator().manual_seed(sum(shape))
+    data = torch.randn(*shape, generator=g)
+    d = data.to(device)
+    assert torch.equal(amax_z(d).cpu(), data.amax(dim=2))
+    flat = torch.zeros(d.numel() + 1, device=device)
+    flat[1:] = d.reshape(-1)
+    off = flat[1:].view(shape)                       # starts 4 bytes past a 16-byte boundary
+    assert torch.equal(amax_z(off).cpu(), data.amax(dim=2))
