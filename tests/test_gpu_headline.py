@@ -43,8 +43,8 @@ def test_headline_launch_64_frames_vs_oracle(device):
     assert occupied > 900_000 * min(n, 8)
 
 
-@pytest.mark.parametrize("fmt", ["records", None])
-@pytest.mark.parametrize("kind,iw,batches", [("label", 0.5, 2), ("label", 1.0, 1), ("ones", 0.5, 2)])
+@pytest.mark.parametrize("kind,iw,batches,fmt", [("label", 0.5, 2, None), ("label", 1.0, 1, None), ("ones", 0.5, 2, None),
+                                                 ("label", 0.5, 2, "records"), ("ones", 0.5, 1, "records")])
 def test_room_batches_fullsize_dense_kernel_vs_oracle(device, monkeypatch, kind, iw, batches, fmt):
     """The kernel behind the room-batch rate at ITS shape: 480x640 -> 256^3 x 54, sequential
     batches of 34 room frames through fuse_dense_kernel (two chunks of 32 + 2 frames per tile, the second
